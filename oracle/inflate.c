@@ -1,0 +1,569 @@
+/*
+ * inflate.c -- raw DEFLATE / zlib / gzip decompression restated on the CPU
+ * (oracle; test infrastructure only, see rsx_oracle.h).
+ *
+ * Follows the portable path of the reference decoder,
+ * src/decompress/mod.rs:213-353 (block state machine), :403-507 (dynamic
+ * header), :509-1072 (Huffman block body), :1324-1495 (decode-table build),
+ * with the table geometry of src/decompress/tables.rs:3-8.
+ *
+ * Two defects of the reference are deliberately NOT restated, because they
+ * corrupt well-formed streams instead of defining behaviour:
+ *   - an end-of-block codeword longer than the litlen root table is not
+ *     recognised after the subtable lookup (src/decompress/mod.rs:941-967 has
+ *     no second END_OF_BLOCK test; src/decompress/x86.rs:2304-2309 consumes it
+ *     but leaves eob_found false).  Here it ends the block, as RFC 1951 says.
+ *   - src/decompress/x86.rs:2208-2213 subtracts 3 from bitsleft without
+ *     checking that 3 bits exist (empty input underflows).  Here, as in
+ *     src/decompress/mod.rs:226-233, that is ShortInput.
+ */
+#include "rsx_oracle.h"
+
+#include <string.h>
+
+#define PRECODE_TABLEBITS 7
+#define PRECODE_ENOUGH 128
+#define LITLEN_TABLEBITS 11
+#define LITLEN_ENOUGH 2342
+#define OFFSET_TABLEBITS 8
+#define OFFSET_ENOUGH 402
+
+#define NUM_PRECODE_SYMS 19
+#define NUM_LITLEN_SYMS 288
+#define NUM_OFFSET_SYMS 32
+#define MAX_CODEWORD_LEN 15
+#define MAX_LENS_OVERRUN 137
+
+/* entry flags, src/decompress/tables.rs:32-35 */
+#define HUFFDEC_LITERAL 0x80000000u
+#define HUFFDEC_EXCEPTIONAL 0x00008000u
+#define HUFFDEC_SUBTABLE_POINTER 0x00004000u
+#define HUFFDEC_END_OF_BLOCK 0x00002000u
+
+typedef struct {
+    uint32_t precode_table[PRECODE_ENOUGH];
+    uint32_t litlen_table[LITLEN_ENOUGH];
+    uint32_t offset_table[OFFSET_ENOUGH];
+    uint8_t precode_lens[NUM_PRECODE_SYMS];
+    uint8_t lens[NUM_LITLEN_SYMS + NUM_OFFSET_SYMS + MAX_LENS_OVERRUN];
+    uint16_t sorted_syms[NUM_LITLEN_SYMS];
+    unsigned litlen_tablebits;
+} inflater;
+
+/* per-symbol decode results, src/decompress/tables.rs:55-379 */
+static const uint16_t len_base[31] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,
+                                      17, 19, 23, 27, 31, 35, 43, 51, 59,  67,  83,
+                                      99, 115, 131, 163, 195, 227, 258, 258, 258};
+static const uint8_t len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+                                      3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
+static const uint16_t off_base[32] = {1,    2,    3,    4,    5,    7,     9,     13,
+                                      17,   25,   33,   49,   65,   97,    129,   193,
+                                      257,  385,  513,  769,  1025, 1537,  2049,  3073,
+                                      4097, 6145, 8193, 12289, 16385, 24577, 24577, 24577};
+static const uint8_t off_extra[32] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,  4,  5,  5,  6,  6,
+                                      7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 13, 13};
+
+enum { KIND_PRECODE, KIND_LITLEN, KIND_OFFSET };
+
+static uint32_t decode_result(int kind, unsigned sym)
+{
+    switch (kind) {
+    case KIND_PRECODE:
+        return sym << 16;
+    case KIND_LITLEN:
+        if (sym < 256)
+            return HUFFDEC_LITERAL | (sym << 16);
+        if (sym == 256)
+            return HUFFDEC_EXCEPTIONAL | HUFFDEC_END_OF_BLOCK;
+        return ((uint32_t)len_base[sym - 257] << 16) | len_extra[sym - 257];
+    default:
+        return ((uint32_t)off_base[sym] << 16) | off_extra[sym];
+    }
+}
+
+/* src/decompress/mod.rs:1319-1322 */
+static uint32_t make_entry(int kind, unsigned sym, unsigned len)
+{
+    return decode_result(kind, sym) + (len << 8) + len;
+}
+
+static unsigned bsr32(uint32_t v) { return 31 - (unsigned)__builtin_clz(v); }
+
+/* src/decompress/mod.rs:1324-1495.  Returns 0 when the code-length set is
+ * rejected. */
+static int build_decode_table(uint32_t *table, const uint8_t *lens, unsigned num_syms,
+                              int kind, unsigned table_bits, unsigned max_codeword_len,
+                              uint16_t *sorted_syms, unsigned *table_bits_ret)
+{
+    unsigned len_counts[MAX_CODEWORD_LEN + 1] = {0};
+    unsigned offsets[MAX_CODEWORD_LEN + 1];
+    unsigned sym, len;
+
+    for (sym = 0; sym < num_syms; sym++)
+        len_counts[lens[sym]]++;
+
+    while (max_codeword_len > 1 && len_counts[max_codeword_len] == 0)
+        max_codeword_len--;
+    if (table_bits_ret) {
+        if (table_bits > max_codeword_len)
+            table_bits = max_codeword_len;
+        *table_bits_ret = table_bits;
+    }
+
+    offsets[0] = 0;
+    offsets[1] = len_counts[0];
+    uint32_t codespace_used = 0;
+    for (len = 1; len < max_codeword_len; len++) {
+        offsets[len + 1] = offsets[len] + len_counts[len];
+        codespace_used = (codespace_used << 1) + len_counts[len];
+    }
+    codespace_used = (codespace_used << 1) + len_counts[max_codeword_len];
+
+    for (sym = 0; sym < num_syms; sym++)
+        sorted_syms[offsets[lens[sym]]++] = (uint16_t)sym;
+
+    if (codespace_used > (1u << max_codeword_len))
+        return 0; /* over-subscribed */
+    if (codespace_used < (1u << max_codeword_len)) {
+        /* incomplete: only the empty code and the lone 1-bit codeword pass
+         * (src/decompress/mod.rs:1368-1383) */
+        unsigned s;
+        if (codespace_used == 0) {
+            s = 0;
+        } else {
+            if (codespace_used != (1u << (max_codeword_len - 1)) || len_counts[1] != 1)
+                return 0;
+            s = sorted_syms[offsets[0]];
+        }
+        uint32_t e = make_entry(kind, s, 1);
+        for (unsigned i = 0; i < (1u << table_bits); i++)
+            table[i] = e;
+        return 1;
+    }
+
+    /* complete code: fill in canonical order, codewords bit-reversed */
+    const uint16_t *sp = sorted_syms + offsets[0];
+    uint32_t codeword = 0;
+    len = 1;
+    while (len_counts[len] == 0)
+        len++;
+    unsigned cur_table_end = 1u << len;
+    while (len <= table_bits) {
+        unsigned count = len_counts[len];
+        while (count--) {
+            table[codeword] = make_entry(kind, *sp++, len);
+            if (codeword == cur_table_end - 1) {
+                /* last codeword: replicate up to the full root table */
+                for (; len < table_bits; len++) {
+                    memcpy(&table[cur_table_end], table, cur_table_end * sizeof(table[0]));
+                    cur_table_end <<= 1;
+                }
+                return 1;
+            }
+            unsigned bit = 1u << bsr32(codeword ^ (cur_table_end - 1));
+            codeword &= bit - 1;
+            codeword |= bit;
+        }
+        do {
+            if (++len <= table_bits) {
+                memcpy(&table[cur_table_end], table, cur_table_end * sizeof(table[0]));
+                cur_table_end <<= 1;
+            }
+        } while (len <= table_bits && len_counts[len] == 0);
+        if (len > table_bits) {
+            while (len_counts[len] == 0)
+                len++;
+        }
+    }
+
+    /* codewords longer than table_bits: subtables */
+    cur_table_end = 1u << table_bits;
+    uint32_t subtable_prefix = ~0u;
+    unsigned subtable_start = 0;
+    for (;;) {
+        if ((codeword & ((1u << table_bits) - 1)) != subtable_prefix) {
+            subtable_prefix = codeword & ((1u << table_bits) - 1);
+            subtable_start = cur_table_end;
+            unsigned subtable_bits = len - table_bits;
+            uint32_t sub_used = len_counts[len];
+            while (sub_used < (1u << subtable_bits)) {
+                subtable_bits++;
+                sub_used = (sub_used << 1) + (table_bits + subtable_bits <= MAX_CODEWORD_LEN
+                                                  ? len_counts[table_bits + subtable_bits]
+                                                  : 0);
+            }
+            cur_table_end = subtable_start + (1u << subtable_bits);
+            table[subtable_prefix] = ((uint32_t)subtable_start << 16) | HUFFDEC_EXCEPTIONAL |
+                                     HUFFDEC_SUBTABLE_POINTER | (subtable_bits << 8) | table_bits;
+        }
+        uint32_t e = make_entry(kind, *sp++, len - table_bits);
+        unsigned stride = 1u << (len - table_bits);
+        for (unsigned i = subtable_start + (codeword >> table_bits); i < cur_table_end; i += stride)
+            table[i] = e;
+        if (codeword == (1u << len) - 1)
+            return 1;
+        unsigned bit = 1u << bsr32(codeword ^ ((1u << len) - 1));
+        codeword &= bit - 1;
+        codeword |= bit;
+        len_counts[len]--;
+        while (len_counts[len] == 0)
+            len++;
+    }
+}
+
+/* bit reader state; refill follows the macro at src/decompress/mod.rs:16-35 */
+typedef struct {
+    const uint8_t *in;
+    size_t in_len;
+    size_t in_idx;
+    uint64_t bitbuf;
+    unsigned bitsleft;
+} bitreader;
+
+static inline void refill(bitreader *b)
+{
+    if (b->bitsleft < 32) {
+        if (b->in_len - b->in_idx >= 8) {
+            uint64_t w;
+            memcpy(&w, b->in + b->in_idx, 8); /* little-endian host */
+            b->bitbuf |= w << b->bitsleft;
+            b->in_idx += (63 - b->bitsleft) >> 3;
+            b->bitsleft |= 56;
+        } else {
+            while (b->bitsleft < 32 && b->in_idx < b->in_len) {
+                b->bitbuf |= (uint64_t)b->in[b->in_idx++] << b->bitsleft;
+                b->bitsleft += 8;
+            }
+        }
+    }
+}
+
+#define TAKE(b, n) ((b)->bitbuf >>= (n), (b)->bitsleft -= (n))
+
+static const uint8_t precode_perm[NUM_PRECODE_SYMS] = {16, 17, 18, 0, 8,  7, 9,  6, 10, 5,
+                                                        11, 4,  12, 3, 13, 2, 14, 1, 15};
+
+/* src/decompress/mod.rs:403-507 */
+static int read_dynamic_header(inflater *d, bitreader *b)
+{
+    refill(b);
+    if (b->bitsleft < 14)
+        return ORC_SHORT_INPUT;
+    unsigned num_litlen = 257 + (b->bitbuf & 0x1F);
+    unsigned num_offset = 1 + ((b->bitbuf >> 5) & 0x1F);
+    unsigned num_precode = 4 + ((b->bitbuf >> 10) & 0xF);
+    TAKE(b, 14);
+    unsigned i;
+    for (i = 0; i < num_precode; i++) {
+        refill(b);
+        if (b->bitsleft < 3)
+            return ORC_SHORT_INPUT;
+        d->precode_lens[precode_perm[i]] = b->bitbuf & 7;
+        TAKE(b, 3);
+    }
+    for (; i < NUM_PRECODE_SYMS; i++)
+        d->precode_lens[precode_perm[i]] = 0;
+    if (!build_decode_table(d->precode_table, d->precode_lens, NUM_PRECODE_SYMS, KIND_PRECODE,
+                            PRECODE_TABLEBITS, 7, d->sorted_syms, NULL))
+        return ORC_BAD_DATA;
+
+    unsigned total = num_litlen + num_offset;
+    i = 0;
+    while (i < total) {
+        refill(b);
+        uint32_t e = d->precode_table[b->bitbuf & ((1u << PRECODE_TABLEBITS) - 1)];
+        unsigned nbits = e & 0xFF;
+        if (b->bitsleft < nbits)
+            return ORC_SHORT_INPUT;
+        TAKE(b, nbits);
+        unsigned presym = e >> 16;
+        unsigned rep, val;
+        if (presym < 16) {
+            d->lens[i++] = (uint8_t)presym;
+            continue;
+        }
+        if (presym == 16) {
+            if (i == 0)
+                return ORC_BAD_DATA;
+            val = d->lens[i - 1];
+            if (b->bitsleft < 2)
+                return ORC_SHORT_INPUT;
+            rep = 3 + (b->bitbuf & 3);
+            TAKE(b, 2);
+        } else if (presym == 17) {
+            val = 0;
+            if (b->bitsleft < 3)
+                return ORC_SHORT_INPUT;
+            rep = 3 + (b->bitbuf & 7);
+            TAKE(b, 3);
+        } else {
+            val = 0;
+            if (b->bitsleft < 7)
+                return ORC_SHORT_INPUT;
+            rep = 11 + (b->bitbuf & 0x7F);
+            TAKE(b, 7);
+        }
+        /* a run that passes the end is clamped, not rejected
+         * (src/decompress/mod.rs:462-467, :475-480, :488-493) */
+        while (rep-- && i < total)
+            d->lens[i++] = (uint8_t)val;
+    }
+    if (!build_decode_table(d->offset_table, d->lens + num_litlen, num_offset, KIND_OFFSET,
+                            OFFSET_TABLEBITS, 15, d->sorted_syms, NULL))
+        return ORC_BAD_DATA;
+    if (!build_decode_table(d->litlen_table, d->lens, num_litlen, KIND_LITLEN, LITLEN_TABLEBITS,
+                            15, d->sorted_syms, &d->litlen_tablebits))
+        return ORC_BAD_DATA;
+    return ORC_SUCCESS;
+}
+
+/* src/decompress/mod.rs:355-401 */
+static void load_static_codes(inflater *d)
+{
+    unsigned i = 0;
+    for (; i < 144; i++) d->lens[i] = 8;
+    for (; i < 256; i++) d->lens[i] = 9;
+    for (; i < 280; i++) d->lens[i] = 7;
+    for (; i < 288; i++) d->lens[i] = 8;
+    for (; i < 288 + 32; i++) d->lens[i] = 5;
+    build_decode_table(d->offset_table, d->lens + 288, 32, KIND_OFFSET, OFFSET_TABLEBITS, 15,
+                       d->sorted_syms, NULL);
+    build_decode_table(d->litlen_table, d->lens, 288, KIND_LITLEN, LITLEN_TABLEBITS, 15,
+                       d->sorted_syms, &d->litlen_tablebits);
+}
+
+/* careful loop of src/decompress/mod.rs:940-1071 (the fast loops at :629-770
+ * and :778-938 decode the same symbols with the same refill points) */
+static int huffman_block(inflater *d, bitreader *b, uint8_t *out, size_t out_len, size_t *out_idx)
+{
+    const uint32_t litlen_mask = (1u << d->litlen_tablebits) - 1;
+    size_t o = *out_idx;
+    for (;;) {
+        refill(b);
+        uint32_t e = d->litlen_table[b->bitbuf & litlen_mask];
+        if (e & HUFFDEC_EXCEPTIONAL) {
+            if (e & HUFFDEC_END_OF_BLOCK) {
+                TAKE(b, e & 0xFF);
+                *out_idx = o;
+                return ORC_SUCCESS;
+            }
+            unsigned main_bits = e & 0xFF;
+            if (b->bitsleft < main_bits) {
+                *out_idx = o;
+                return ORC_SHORT_INPUT;
+            }
+            TAKE(b, main_bits);
+            e = d->litlen_table[(e >> 16) + (b->bitbuf & ((1u << ((e >> 8) & 0x3F)) - 1))];
+        }
+        uint64_t saved = b->bitbuf;
+        unsigned total_bits = e & 0xFF;
+        if (b->bitsleft < total_bits) {
+            *out_idx = o;
+            return ORC_SHORT_INPUT;
+        }
+        TAKE(b, total_bits);
+        if (e & HUFFDEC_LITERAL) {
+            if (o >= out_len) {
+                *out_idx = o;
+                return ORC_INSUFFICIENT_SPACE;
+            }
+            out[o++] = (uint8_t)(e >> 16);
+            continue;
+        }
+        if (e & HUFFDEC_END_OF_BLOCK) { /* end-of-block reached through a subtable */
+            *out_idx = o;
+            return ORC_SUCCESS;
+        }
+        size_t length = e >> 16;
+        unsigned len = (e >> 8) & 0xFF;
+        length += (saved >> len) & ((1u << (total_bits - len)) - 1);
+
+        refill(b);
+        e = d->offset_table[b->bitbuf & ((1u << OFFSET_TABLEBITS) - 1)];
+        if (e & HUFFDEC_SUBTABLE_POINTER) {
+            unsigned main_bits = e & 0xFF;
+            if (b->bitsleft < main_bits) {
+                *out_idx = o;
+                return ORC_SHORT_INPUT;
+            }
+            TAKE(b, main_bits);
+            e = d->offset_table[(e >> 16) + (b->bitbuf & ((1u << ((e >> 8) & 0x3F)) - 1))];
+        }
+        saved = b->bitbuf;
+        total_bits = e & 0xFF;
+        if (b->bitsleft < total_bits) {
+            *out_idx = o;
+            return ORC_SHORT_INPUT;
+        }
+        TAKE(b, total_bits);
+        size_t offset = e >> 16;
+        len = (e >> 8) & 0xFF;
+        offset += (saved >> len) & ((1u << (total_bits - len)) - 1);
+        *out_idx = o;
+        if (offset > o)
+            return ORC_BAD_DATA;
+        if (o + length > out_len)
+            return ORC_INSUFFICIENT_SPACE;
+        /* every copy specialisation in the reference equals this byte-serial
+         * copy (overlap repeats the last `offset` bytes) */
+        const uint8_t *src = out + o - offset;
+        uint8_t *dst = out + o;
+        for (size_t k = 0; k < length; k++)
+            dst[k] = src[k];
+        o += length;
+    }
+}
+
+/* src/decompress/mod.rs:213-353, entered in state Start with an empty bit
+ * buffer as decompress_ptr does (:195-201). */
+static int inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
+                       size_t *in_consumed, size_t *out_produced)
+{
+    inflater d;
+    bitreader b = {in, in_len, 0, 0, 0};
+    size_t o = 0;
+    int res;
+    for (;;) {
+        refill(&b);
+        if (b.bitsleft < 3) {
+            res = ORC_SHORT_INPUT;
+            break;
+        }
+        int is_final = b.bitbuf & 1;
+        unsigned type = (b.bitbuf >> 1) & 3;
+        TAKE(&b, 3);
+        if (type == 0) {
+            /* :282-346 */
+            unsigned skip = b.bitsleft & 7;
+            TAKE(&b, skip);
+            size_t unused = b.bitsleft / 8;
+            b.in_idx = b.in_idx >= unused ? b.in_idx - unused : 0;
+            b.bitbuf = 0;
+            b.bitsleft = 0;
+            if (b.in_idx + 4 > in_len) {
+                res = ORC_SHORT_INPUT;
+                break;
+            }
+            unsigned len = in[b.in_idx] | (in[b.in_idx + 1] << 8);
+            unsigned nlen = in[b.in_idx + 2] | (in[b.in_idx + 3] << 8);
+            b.in_idx += 4;
+            if (len != (~nlen & 0xFFFF)) {
+                res = ORC_BAD_DATA;
+                break;
+            }
+            size_t avail_in = in_len - b.in_idx, avail_out = out_len - o;
+            size_t n = len;
+            if (n > avail_in) n = avail_in;
+            if (n > avail_out) n = avail_out;
+            memcpy(out + o, in + b.in_idx, n);
+            b.in_idx += n;
+            o += n;
+            if (n < len) {
+                /* whichever side ran dry first; a tie reports the output side
+                 * (:329-344) */
+                res = avail_out <= avail_in ? ORC_INSUFFICIENT_SPACE : ORC_SHORT_INPUT;
+                break;
+            }
+        } else if (type == 3) {
+            res = ORC_BAD_DATA;
+            break;
+        } else {
+            if (type == 2) {
+                res = read_dynamic_header(&d, &b);
+                if (res != ORC_SUCCESS)
+                    break;
+            } else {
+                load_static_codes(&d);
+            }
+            res = huffman_block(&d, &b, out, out_len, &o);
+            if (res != ORC_SUCCESS)
+                break;
+        }
+        if (is_final) {
+            res = ORC_SUCCESS;
+            break;
+        }
+    }
+    *in_consumed = b.in_idx;
+    *out_produced = o;
+    return res;
+}
+
+static uint32_t le32(const uint8_t *p)
+{
+    return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+int orc_decompress(int format, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                   size_t *in_consumed, size_t *out_produced)
+{
+    size_t ic = 0, op = 0;
+    int res;
+    if (format == ORC_FMT_DEFLATE) {
+        res = inflate_raw(in, in_len, out, out_cap, &ic, &op);
+    } else if (format == ORC_FMT_ZLIB) {
+        /* src/decompress/mod.rs:1074-1127 */
+        if (in_len < 6) {
+            res = ORC_SHORT_INPUT;
+        } else {
+            unsigned hdr = (in[0] << 8) | in[1];
+            if (hdr % 31 != 0 || ((hdr >> 8) & 0xF) != 8 || ((hdr >> 12) & 0xF) > 7 ||
+                ((hdr >> 5) & 1)) {
+                res = ORC_BAD_DATA;
+            } else {
+                res = inflate_raw(in + 2, in_len - 6, out, out_cap, &ic, &op);
+                ic += 2;
+                if (res == ORC_SUCCESS) {
+                    const uint8_t *f = in + ic;
+                    uint32_t want =
+                        ((uint32_t)f[0] << 24) | (f[1] << 16) | (f[2] << 8) | f[3];
+                    ic += 4;
+                    if (orc_adler32(1, out, op) != want)
+                        res = ORC_BAD_DATA;
+                }
+            }
+        }
+    } else {
+        /* src/decompress/mod.rs:1144-1240 */
+        res = -1;
+        size_t h = 10;
+        if (in_len < 18) {
+            res = ORC_SHORT_INPUT;
+        } else if (in[0] != 0x1F || in[1] != 0x8B || in[2] != 8 || (in[3] & 0xE0)) {
+            res = ORC_BAD_DATA;
+        } else {
+            unsigned flg = in[3];
+            if (flg & 0x04) {
+                if (h + 2 > in_len)
+                    res = ORC_SHORT_INPUT;
+                else
+                    h += 2 + (in[h] | (in[h + 1] << 8));
+            }
+            if (res < 0 && (flg & 0x08)) {
+                while (h < in_len && in[h] != 0) h++;
+                h++;
+            }
+            if (res < 0 && (flg & 0x10)) {
+                while (h < in_len && in[h] != 0) h++;
+                h++;
+            }
+            if (res < 0 && (flg & 0x02))
+                h += 2;
+            if (res < 0 && h + 8 > in_len)
+                res = ORC_SHORT_INPUT;
+        }
+        if (res < 0) {
+            res = inflate_raw(in + h, in_len - 8 - h, out, out_cap, &ic, &op);
+            ic += h;
+            if (res == ORC_SUCCESS) {
+                uint32_t want_crc = le32(in + ic), want_isize = le32(in + ic + 4);
+                ic += 8;
+                if (orc_crc32(0, out, op) != want_crc || (uint32_t)op != want_isize)
+                    res = ORC_BAD_DATA;
+            }
+        }
+    }
+    if (in_consumed) *in_consumed = ic;
+    if (out_produced) *out_produced = op;
+    return res;
+}
