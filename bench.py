@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batch gzip decompress of 4096 x 1 MiB level-6 text
+buffers per GPU (BASELINE.json configs[1]), reported as GiB/s of bytes in + out.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  Streams are independent, so ranks shard the batch with no
+data-path collective (weak scaling: every rank decodes its own 4096 streams);
+RCCL is used only for the start/stop barrier and the max-over-ranks reduce.
+
+A step = one rsx_batch_decompress_device call over the whole per-rank batch,
+inputs and outputs resident in HBM.  The compressed streams are produced by the
+CPU restatement of the reference compressor (gzip, level 6, four sync-flushed
+256 KiB segments per buffer); `--distinct` different buffers are generated and
+physically replicated in device memory to the full batch so every stream is
+read from its own addresses.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def host_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))  # a 1-GPU box shares 16 host cores
+
+
+def make_streams(distinct, buf_bytes, fmt, level, seed0):
+    import corpus
+    import oracle_lib as orc
+    texts = [corpus.text(buf_bytes, seed0 + i) for i in range(distinct)]
+    flat = np.frombuffer(b"".join(texts), dtype=np.uint8)
+    in_off = np.arange(distinct + 1, dtype=np.uint64) * np.uint64(buf_bytes)
+    out, out_off, sizes, status = orc.batch_compress(flat, in_off, fmt, level, threads=host_threads())
+    assert (status == 0).all(), "oracle compressor failed on synthetic text"
+    streams = [out[int(out_off[i]):int(out_off[i]) + int(sizes[i])] for i in range(distinct)]
+    return texts, streams
+
+
+def cpu_baseline(streams, buf_bytes, fmt, target_s=12.0):
+    """Times the CPU restatement of the reference decoder on the distinct streams
+    (all host threads the box grants), repeated until ~target_s of work."""
+    import oracle_lib as orc
+    th = host_threads()
+    d = len(streams)
+    flat = np.concatenate(streams)
+    in_off = np.zeros(d + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in streams], out=in_off[1:])
+    out_off = np.arange(d + 1, dtype=np.uint64) * np.uint64(buf_bytes)
+    t0 = time.perf_counter()
+    orc.batch_decompress(flat, in_off, out_off, fmt, threads=th)  # warm-up + rate estimate
+    once = time.perf_counter() - t0
+    reps = int(max(1, min(50, target_s / max(once, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _, sizes, status = orc.batch_decompress(flat, in_off, out_off, fmt, threads=th)
+    dt = time.perf_counter() - t0
+    assert (status == 0).all()
+    nbytes = reps * (int(in_off[-1]) + int(sizes.sum()))
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": th, "kind": "port",
+            "sample": "%d x %d distinct streams of the same workload, %d passes, %.1f s"
+                      % (reps, d, reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
+    ap.add_argument("--buf-kib", type=int, default=1024, help="uncompressed KiB per stream")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct buffers generated on the CPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rsx_pkg
+    rsx = rsx_pkg.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    fmt, level = rsx.FORMAT_GZIP, 6
+    buf = args.buf_kib * 1024
+    n = args.streams
+    distinct = min(args.distinct, n)
+    texts, streams = make_streams(distinct, buf, fmt, level, seed0=1000 * rank)
+
+    # replicate to the full batch: stream i is a private copy of distinct stream i % distinct
+    lens = np.array([len(streams[i % distinct]) for i in range(n)], dtype=np.uint64)
+    in_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=in_off[1:])
+    total_in = int(in_off[-1])
+    h_in = np.empty(total_in, dtype=np.uint8)
+    for i in range(n):
+        h_in[int(in_off[i]):int(in_off[i + 1])] = streams[i % distinct]
+    out_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)
+    total_out = n * buf
+
+    d_in = torch.from_numpy(h_in).to(dev)
+    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
+    d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
+    d_out = torch.empty(total_out, dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    del h_in
+
+    stream = torch.cuda.current_stream(dev)
+    eng = rsx.Engine(local_rank, stream.cuda_stream)
+
+    def step():
+        eng.batch_decompress_device(fmt, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, total_out,
+                                    buf, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                    d_status.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(None)
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-launch kernel time: a second, separately timed loop so reading the
+    # events does not serialise the timed region above
+    for k in range(args.steps):
+        step()
+        kernel_ms[k] = eng.last_kernel_ms()
+    torch.cuda.synchronize(dev)
+
+    # verification outside the timed region: every status 0, sizes exact, and the
+    # first `distinct` outputs byte-identical to the original texts
+    st = d_status.cpu().numpy()
+    sz = d_sizes.cpu().numpy()
+    ok = bool((st == 0).all() and (sz == buf).all())
+    host_out = d_out[: distinct * buf].cpu().numpy()
+    for i in range(distinct):
+        ok = ok and host_out[i * buf:(i + 1) * buf].tobytes() == texts[i]
+    if not ok:
+        raise SystemExit("bench.py: GPU output does not match the input texts (status %s)"
+                         % np.unique(st))
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        b = torch.tensor([total_in + total_out], dtype=torch.int64, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        job_bytes = int(b.item())
+    else:
+        job_bytes = total_in + total_out
+
+    if rank == 0:
+        alg_bytes = total_in + total_out  # per launch on this rank
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        res = {
+            "metric": "batch GiB/s in+out (compress@L6, decompress) at 1/2/4/8 GPUs; % HBM roofline",
+            "value": job_bytes * args.steps / dt / 2**30,
+            "unit": "GiB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "batch gzip decompress, %d x %d KiB level-6 enwik-style text per GPU"
+                            % (n, args.buf_kib),
+                "op": "decompress", "format": "gzip", "level": level, "streams_per_gpu": n,
+                "buf_bytes": buf, "distinct_buffers": distinct,
+                "compressed_ratio": total_out / total_in,
+                "compressor": "CPU restatement of the reference, 256 KiB sync-flushed segments",
+                "parallelism": "batch sharded over %d GPU(s), no data-path collective" % world,
+                "verified": ok,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "inflate_kernel", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(streams, buf, fmt)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

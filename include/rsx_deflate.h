@@ -1,0 +1,146 @@
+/*
+ * rsx_deflate.h -- C ABI of librsx_deflate.so, the MI355X (gfx950) batch
+ * DEFLATE engine that sits behind libdeflate-rsx's batch API.
+ *
+ * The reference crate exports no C symbols; its only accelerator hook is
+ * `CudaBatchCompressor` (src/batch_cuda.rs:20, :43-46), called from
+ * `BatchCompressor::compress_batch` (src/batch.rs:21-32).  These entry points
+ * are what a `HipBatchCompressor` / `HipBatchDecompressor` in that position
+ * binds: the same flat-buffer + u64-offset layout that src/batch_cuda.rs:57-87
+ * builds for its kernel (src/cuda/compress.cu:1-8), plain pointers and sizes.
+ *
+ * Conventions
+ *   - Every function returns RSX_OK (0) or a negative RSX_E_* engine error.  An
+ *     engine error means "nothing usable was produced": the Rust shim returns
+ *     Err and the caller falls back to the CPU path (src/batch.rs:28-30).
+ *   - Per-item results are reported in status[i] with the reference's own
+ *     codes and out_sizes[i] (0 on failure); one bad item never fails the
+ *     batch (src/batch.rs:52-54, :95-97).
+ *   - Item i reads  in[in_off[i] .. in_off[i+1])           (n+1 offsets) and
+ *     may write     out[out_off[i] .. out_off[i+1])         (n+1 offsets).
+ *     Nothing outside slot i is written for item i.
+ *   - The library never allocates memory the caller can see.
+ *   - An engine is bound to one GPU.  Calls on one engine serialise on an
+ *     internal mutex; use one engine per thread (or per process/GPU) for
+ *     concurrency.
+ */
+#ifndef RSX_DEFLATE_H
+#define RSX_DEFLATE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* engine-level return codes */
+#define RSX_OK 0
+#define RSX_E_INVALID (-1)  /* bad argument (null pointer, level, format) */
+#define RSX_E_DEVICE (-2)   /* HIP runtime error; see rsx_engine_last_error */
+#define RSX_E_NOMEM (-3)    /* device workspace allocation failed */
+
+/* container formats: raw DEFLATE (batch.rs), zlib, gzip (src/api.rs:22-57) */
+#define RSX_FORMAT_DEFLATE 0
+#define RSX_FORMAT_ZLIB 1
+#define RSX_FORMAT_GZIP 2
+
+/* per-item decompress status = DecompressResult, src/decompress/mod.rs:77-85 */
+#define RSX_SUCCESS 0
+#define RSX_BAD_DATA 1
+#define RSX_SHORT_OUTPUT 2
+#define RSX_INSUFFICIENT_SPACE 3
+#define RSX_SHORT_INPUT 4
+/* per-item compress status = CompressResult, src/compress/mod.rs:238-241:
+ * 0 Success, 1 InsufficientSpace */
+#define RSX_COMPRESS_INSUFFICIENT_SPACE 1
+
+/* checksum kinds for rsx_batch_checksum* */
+#define RSX_CHECKSUM_CRC32 0   /* src/crc32/mod.rs:332-365 */
+#define RSX_CHECKSUM_ADLER32 1 /* src/adler32/mod.rs:115-152 */
+
+typedef struct rsx_engine rsx_engine;
+
+/*
+ * Replaces CudaBatchCompressor::new (src/batch_cuda.rs:20-41, which opens
+ * device 0): binds an engine to GPU `device`.  `stream` is a hipStream_t to
+ * launch on, or NULL to let the engine create its own.
+ */
+int rsx_engine_create(int device, void *stream, rsx_engine **out);
+void rsx_engine_destroy(rsx_engine *e);
+/* last HIP / argument error text of this engine (valid until the next call) */
+const char *rsx_engine_last_error(const rsx_engine *e);
+/* the hipStream_t all work of this engine is launched on */
+void *rsx_engine_stream(const rsx_engine *e);
+/* blocks until everything queued by *_device calls has finished */
+int rsx_engine_synchronize(rsx_engine *e);
+/*
+ * Duration in milliseconds of the dominant kernel of the most recent
+ * *_device call (inflate, deflate or checksum kernel), measured with HIP
+ * events on the engine's stream.  Synchronises.  Negative if none was run.
+ */
+float rsx_engine_last_kernel_ms(rsx_engine *e);
+
+/* Compressor::{deflate,zlib,gzip}_compress_bound, src/compress/mod.rs:2236-2246 */
+uint64_t rsx_compress_bound(int format, uint64_t len);
+
+/*
+ * Replaces CudaBatchCompressor::compress_batch (src/batch_cuda.rs:43-150) and
+ * the CPU loop it shadows (src/batch.rs:34-57).  Host pointers; returns after
+ * results are in `out`.  level 0..12 as in src/api.rs:10-20.  Slot i should be
+ * at least rsx_compress_bound(format, len_i) bytes; status[i] = 1 and
+ * out_sizes[i] = 0 if the stream does not fit.
+ */
+int rsx_batch_compress(rsx_engine *e, int format, int level, const uint8_t *in,
+                       const uint64_t *in_off, size_t n, uint8_t *out, const uint64_t *out_off,
+                       uint64_t *out_sizes, int32_t *status);
+
+/*
+ * GPU counterpart of BatchDecompressor::decompress_batch (src/batch.rs:74-101;
+ * the reference has no accelerator hook there).  Slot size i is the item's
+ * max_out_sizes[i].  status[i] = DecompressResult; out_sizes[i] = bytes
+ * produced on success.  For zlib / gzip the Adler-32 / CRC-32 + ISIZE trailer
+ * is verified (src/decompress/mod.rs:1074-1240) and a mismatch is BadData.
+ */
+int rsx_batch_decompress(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off,
+                         size_t n, uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
+                         int32_t *status);
+
+/*
+ * crc32 / adler32 (src/crc32/mod.rs:332, src/adler32/mod.rs:115) over every
+ * item of a batch: values[i] = f(init, item i), init = 0 for CRC-32 and 1 for
+ * Adler-32 when starting a new checksum.  Host pointers.
+ */
+int rsx_batch_checksum(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
+                       const uint64_t *in_off, size_t n, uint32_t *values);
+/* single-buffer convenience forms of the crate's public crc32()/adler32()
+ * (src/lib.rs:15-17); *value receives the result */
+int rsx_crc32(rsx_engine *e, uint32_t crc, const uint8_t *data, size_t len, uint32_t *value);
+int rsx_adler32(rsx_engine *e, uint32_t adler, const uint8_t *data, size_t len, uint32_t *value);
+
+/*
+ * Device-resident variants: every pointer is device memory on the engine's
+ * GPU, the work is queued on the engine's stream and the call returns without
+ * waiting (use rsx_engine_synchronize or stream ordering).  They replace the
+ * H2D / launch / D2H sequence of src/batch_cuda.rs:81-141 for callers whose
+ * data already lives in HBM.  total_in = in_off[n] - in_off[0], max_item (the
+ * largest item's input length) and, for decompress, total_out / max_out (sum
+ * and maximum of the output slot sizes) are host-known scalars used to size
+ * the launch and the workspace.  Items must be smaller than 4 GiB.
+ */
+int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_t *in,
+                              const uint64_t *in_off, size_t n, uint64_t total_in,
+                              uint64_t max_item, uint8_t *out, const uint64_t *out_off,
+                              uint64_t *out_sizes, int32_t *status);
+int rsx_batch_decompress_device(rsx_engine *e, int format, const uint8_t *in,
+                                const uint64_t *in_off, size_t n, uint64_t total_in,
+                                uint64_t total_out, uint64_t max_out, uint8_t *out,
+                                const uint64_t *out_off, uint64_t *out_sizes, int32_t *status);
+int rsx_batch_checksum_device(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
+                              const uint64_t *in_off, size_t n, uint64_t total_in,
+                              uint64_t max_item, uint32_t *values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,372 @@
+// api.cpp -- the extern "C" surface declared in include/rsx_deflate.h: engine
+// lifetime, workspace management, and the host-pointer wrappers that stage
+// through device memory the way src/batch_cuda.rs:81-141 does (H2D, launch,
+// D2H) around the *_device entry points.
+#include "engine.h"
+
+#include <cstring>
+#include <new>
+
+int ws_reserve(rsx_engine *e, size_t bytes)
+{
+    e->ws_used = 0;
+    if (bytes <= e->ws_size) return RSX_OK;
+    if (e->ws) {
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+        RSX_HIP(e, hipFree(e->ws));
+        e->ws = nullptr;
+        e->ws_size = 0;
+    }
+    size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    if (hipMalloc(reinterpret_cast<void **>(&e->ws), want) != hipSuccess) {
+        (void)hipGetLastError();
+        e->err = "device workspace allocation of " + std::to_string(want) + " bytes failed";
+        return RSX_E_NOMEM;
+    }
+    e->ws_size = want;
+    return RSX_OK;
+}
+
+void *ws_take(rsx_engine *e, size_t bytes)
+{
+    size_t at = align_up(e->ws_used, 256);
+    if (at + bytes > e->ws_size) return nullptr;
+    e->ws_used = at + bytes;
+    return e->ws + at;
+}
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int bad(rsx_engine *e, const char *msg)
+{
+    if (e) e->err = msg;
+    return RSX_E_INVALID;
+}
+
+bool format_ok(int f) { return f >= RSX_FORMAT_DEFLATE && f <= RSX_FORMAT_GZIP; }
+
+void time_begin(rsx_engine *e) { (void)hipEventRecord(e->ev_begin, e->stream); }
+void time_end(rsx_engine *e)
+{
+    (void)hipEventRecord(e->ev_end, e->stream);
+    e->timed = true;
+}
+
+// host-side view of a batch: validates offsets and derives the scalars the
+// device entry points want
+struct BatchShape {
+    uint64_t total = 0, max_item = 0;
+};
+
+bool shape_of(const uint64_t *off, size_t n, BatchShape *s)
+{
+    s->total = n ? off[n] - off[0] : 0;
+    s->max_item = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (off[i + 1] < off[i]) return false;
+        uint64_t l = off[i + 1] - off[i];
+        if (l > s->max_item) s->max_item = l;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsx_engine_create(int device, void *stream, rsx_engine **out)
+{
+    if (!out) return RSX_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return RSX_E_DEVICE;
+    rsx_engine *e = new (std::nothrow) rsx_engine();
+    if (!e) return RSX_E_NOMEM;
+    e->device = device;
+    DeviceGuard g(device);
+    if (stream) {
+        e->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete e;
+            return RSX_E_DEVICE;
+        }
+        e->own_stream = true;
+    }
+    if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess ||
+        checksum_tables_create(e) != RSX_OK) {
+        rsx_engine_destroy(e);
+        return RSX_E_DEVICE;
+    }
+    *out = e;
+    return RSX_OK;
+}
+
+void rsx_engine_destroy(rsx_engine *e)
+{
+    if (!e) return;
+    DeviceGuard g(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->ws) (void)hipFree(e->ws);
+    if (e->d_crc_tables) (void)hipFree(e->d_crc_tables);
+    if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
+    if (e->ev_end) (void)hipEventDestroy(e->ev_end);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char *rsx_engine_last_error(const rsx_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+void *rsx_engine_stream(const rsx_engine *e) { return e ? e->stream : nullptr; }
+
+int rsx_engine_synchronize(rsx_engine *e)
+{
+    if (!e) return RSX_E_INVALID;
+    DeviceGuard g(e->device);
+    RSX_HIP(e, hipStreamSynchronize(e->stream));
+    return RSX_OK;
+}
+
+float rsx_engine_last_kernel_ms(rsx_engine *e)
+{
+    if (!e || !e->timed) return -1.0f;
+    DeviceGuard g(e->device);
+    float ms = -1.0f;
+    if (hipEventSynchronize(e->ev_end) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+uint64_t rsx_compress_bound(int format, uint64_t len)
+{
+    uint64_t b = len + (len / 65535 + 1) * 5 + 10;
+    if (format == RSX_FORMAT_ZLIB) b += 6;
+    if (format == RSX_FORMAT_GZIP) b += 18;
+    return b;
+}
+
+// ---- device-resident entry points -------------------------------------------
+
+int rsx_batch_checksum_device(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
+                              const uint64_t *in_off, size_t n, uint64_t total_in,
+                              uint64_t max_item, uint32_t *values)
+{
+    if (!e) return RSX_E_INVALID;
+    if (kind != RSX_CHECKSUM_CRC32 && kind != RSX_CHECKSUM_ADLER32) return bad(e, "bad checksum kind");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !values || (!in && total_in)) return bad(e, "null pointer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    int r = ws_reserve(e, checksum_ws_bytes(n, total_in));
+    if (r != RSX_OK) return r;
+    time_begin(e);
+    r = checksum_launch(e, kind, init, in, in_off, nullptr, n, total_in, max_item, values);
+    time_end(e);
+    return r;
+}
+
+int rsx_batch_decompress_device(rsx_engine *e, int format, const uint8_t *in,
+                                const uint64_t *in_off, size_t n, uint64_t total_in,
+                                uint64_t total_out, uint64_t max_out, uint8_t *out,
+                                const uint64_t *out_off, uint64_t *out_sizes, int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (!format_ok(format)) return bad(e, "bad format");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    int r = ws_reserve(e, inflate_ws_bytes(n, total_out));
+    if (r != RSX_OK) return r;
+    return inflate_launch(e, format, in, in_off, n, total_in, total_out, max_out, out, out_off,
+                          out_sizes, status);
+}
+
+int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_t *in,
+                              const uint64_t *in_off, size_t n, uint64_t total_in,
+                              uint64_t max_item, uint8_t *out, const uint64_t *out_off,
+                              uint64_t *out_sizes, int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (!format_ok(format)) return bad(e, "bad format");
+    if (level < 0 || level > 12) return bad(e, "Compression level must be between 0 and 12");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    int r = ws_reserve(e, deflate_ws_bytes(n, total_in, max_item));
+    if (r != RSX_OK) return r;
+    return deflate_launch(e, format, level, in, in_off, n, total_in, max_item, out, out_off,
+                          out_sizes, status);
+}
+
+// ---- host-pointer entry points ------------------------------------------------
+
+namespace {
+
+// Device staging for one host call: flat input, both offset arrays (rebased so
+// that item 0 starts at 0), flat output, sizes, status.
+struct Staged {
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint64_t *d_in_off = nullptr, *d_out_off = nullptr, *d_sizes = nullptr;
+    int32_t *d_status = nullptr;
+    uint32_t *d_values = nullptr;
+};
+
+}  // namespace
+
+static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind, uint32_t init,
+                         const uint8_t *in, const uint64_t *in_off, size_t n, uint8_t *out,
+                         const uint64_t *out_off, uint64_t *out_sizes, int32_t *status,
+                         uint32_t *values)
+{
+    BatchShape si, so;
+    if (!shape_of(in_off, n, &si)) return bad(e, "in_off not monotonic");
+    if (out_off && !shape_of(out_off, n, &so)) return bad(e, "out_off not monotonic");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+
+    size_t kernel_ws = op == 0   ? deflate_ws_bytes(n, si.total, si.max_item)
+                       : op == 1 ? inflate_ws_bytes(n, so.total)
+                                 : checksum_ws_bytes(n, si.total);
+    size_t need = kernel_ws + align_up(si.total + 64, 256) + align_up(so.total + 64, 256) +
+                  4 * align_up((n + 1) * sizeof(uint64_t), 256) + 2 * align_up(n * 4, 256) + 4096;
+    int r = ws_reserve(e, need);
+    if (r != RSX_OK) return r;
+
+    Staged s;
+    s.d_in = static_cast<uint8_t *>(ws_take(e, si.total + 64));
+    s.d_in_off = static_cast<uint64_t *>(ws_take(e, (n + 1) * sizeof(uint64_t)));
+    if (out_off) {
+        s.d_out = static_cast<uint8_t *>(ws_take(e, so.total + 64));
+        s.d_out_off = static_cast<uint64_t *>(ws_take(e, (n + 1) * sizeof(uint64_t)));
+        s.d_sizes = static_cast<uint64_t *>(ws_take(e, n * sizeof(uint64_t)));
+        s.d_status = static_cast<int32_t *>(ws_take(e, n * sizeof(int32_t)));
+    } else {
+        s.d_values = static_cast<uint32_t *>(ws_take(e, n * sizeof(uint32_t)));
+    }
+
+    // rebase offsets to the staged copies
+    std::string &err = e->err;
+    (void)err;
+    uint64_t *h_off = new (std::nothrow) uint64_t[2 * (n + 1)];
+    if (!h_off) return RSX_E_NOMEM;
+    for (size_t i = 0; i <= n; i++) h_off[i] = in_off[i] - in_off[0];
+    if (out_off)
+        for (size_t i = 0; i <= n; i++) h_off[n + 1 + i] = out_off[i] - out_off[0];
+    hipError_t st = hipSuccess;
+    if (si.total)
+        st = hipMemcpyAsync(s.d_in, in + in_off[0], si.total, hipMemcpyHostToDevice, e->stream);
+    if (st == hipSuccess)
+        st = hipMemcpyAsync(s.d_in_off, h_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                            e->stream);
+    if (st == hipSuccess && out_off)
+        st = hipMemcpyAsync(s.d_out_off, h_off + n + 1, (n + 1) * sizeof(uint64_t),
+                            hipMemcpyHostToDevice, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    delete[] h_off;
+    if (st != hipSuccess) {
+        e->err = std::string("staging copy: ") + hipGetErrorString(st);
+        return RSX_E_DEVICE;
+    }
+
+    if (op == 0)
+        r = deflate_launch(e, format, level, s.d_in, s.d_in_off, n, si.total, si.max_item, s.d_out,
+                           s.d_out_off, s.d_sizes, s.d_status);
+    else if (op == 1)
+        r = inflate_launch(e, format, s.d_in, s.d_in_off, n, si.total, so.total, so.max_item,
+                           s.d_out, s.d_out_off, s.d_sizes, s.d_status);
+    else
+        r = checksum_launch(e, kind, init, s.d_in, s.d_in_off, nullptr, n, si.total, si.max_item,
+                            s.d_values);
+    if (r != RSX_OK) return r;
+
+    if (out_off) {
+        RSX_HIP(e, hipMemcpyAsync(out_sizes, s.d_sizes, n * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                  e->stream));
+        RSX_HIP(e, hipMemcpyAsync(status, s.d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  e->stream));
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+        // copy back only what each item produced; sizes are validated against the
+        // slot like src/batch_cuda.rs:123-137 does before touching the payload
+        for (size_t i = 0; i < n; i++) {
+            uint64_t slot = out_off[i + 1] - out_off[i];
+            if (out_sizes[i] > slot) {
+                e->err = "device returned a size larger than its slot";
+                return RSX_E_DEVICE;
+            }
+            if (status[i] == 0 && out_sizes[i])
+                RSX_HIP(e, hipMemcpyAsync(out + out_off[i], s.d_out + (out_off[i] - out_off[0]),
+                                          out_sizes[i], hipMemcpyDeviceToHost, e->stream));
+        }
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+    } else {
+        RSX_HIP(e, hipMemcpyAsync(values, s.d_values, n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                  e->stream));
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return RSX_OK;
+}
+
+int rsx_batch_compress(rsx_engine *e, int format, int level, const uint8_t *in,
+                       const uint64_t *in_off, size_t n, uint8_t *out, const uint64_t *out_off,
+                       uint64_t *out_sizes, int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (!format_ok(format)) return bad(e, "bad format");
+    if (level < 0 || level > 12) return bad(e, "Compression level must be between 0 and 12");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    return stage_and_run(e, 0, format, level, 0, 0, in, in_off, n, out, out_off, out_sizes, status,
+                         nullptr);
+}
+
+int rsx_batch_decompress(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off,
+                         size_t n, uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
+                         int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (!format_ok(format)) return bad(e, "bad format");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    return stage_and_run(e, 1, format, 0, 0, 0, in, in_off, n, out, out_off, out_sizes, status,
+                         nullptr);
+}
+
+int rsx_batch_checksum(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
+                       const uint64_t *in_off, size_t n, uint32_t *values)
+{
+    if (!e) return RSX_E_INVALID;
+    if (kind != RSX_CHECKSUM_CRC32 && kind != RSX_CHECKSUM_ADLER32) return bad(e, "bad checksum kind");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !values) return bad(e, "null pointer");
+    return stage_and_run(e, 2, 0, 0, kind, init, in, in_off, n, nullptr, nullptr, nullptr, nullptr,
+                         values);
+}
+
+int rsx_crc32(rsx_engine *e, uint32_t crc, const uint8_t *data, size_t len, uint32_t *value)
+{
+    uint64_t off[2] = {0, len};
+    return rsx_batch_checksum(e, RSX_CHECKSUM_CRC32, crc, data, off, 1, value);
+}
+
+int rsx_adler32(rsx_engine *e, uint32_t adler, const uint8_t *data, size_t len, uint32_t *value)
+{
+    uint64_t off[2] = {0, len};
+    return rsx_batch_checksum(e, RSX_CHECKSUM_ADLER32, adler, data, off, 1, value);
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// engine.h -- internal state of an rsx_engine and the launch helpers shared by
+// the kernel translation units.  Not part of the public ABI (include/rsx_deflate.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+
+#include "../../include/rsx_deflate.h"
+
+struct rsx_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+    std::string err;
+
+    // grow-only device workspace, carved per call by ws_take()
+    uint8_t *ws = nullptr;
+    size_t ws_size = 0;
+    size_t ws_used = 0;
+
+    // constant tables in device memory (built once in rsx_engine_create)
+    uint32_t *d_crc_tables = nullptr;  // see checksum.hip for the layout
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timed = false;
+};
+
+#define RSX_HIP(e, call)                                                              \
+    do {                                                                              \
+        hipError_t _st = (call);                                                      \
+        if (_st != hipSuccess) {                                                      \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_st);            \
+            return RSX_E_DEVICE;                                                      \
+        }                                                                             \
+    } while (0)
+
+// Ensures the workspace holds at least `bytes` and resets the carve pointer.
+int ws_reserve(rsx_engine *e, size_t bytes);
+// Carves `bytes` (256-byte aligned) out of the reserved workspace; nullptr if exhausted.
+void *ws_take(rsx_engine *e, size_t bytes);
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- kernel launchers (each defined next to its kernels) ---------------------
+
+// checksum.hip
+int checksum_tables_create(rsx_engine *e);
+size_t checksum_ws_bytes(size_t n, uint64_t total_in);
+// items are in[starts[i] .. starts[i] + len_i) with len_i = lens ? lens[i] : starts[i+1]-starts[i];
+// total_in bounds the sum of lengths, max_item the largest one
+int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
+                    const uint64_t *starts, const uint64_t *lens, size_t n, uint64_t total_in,
+                    uint64_t max_item, uint32_t *values);
+
+// inflate.hip
+size_t inflate_ws_bytes(size_t n, uint64_t total_out);
+// total_out / max_out: sum and maximum of the output slot sizes
+int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off, size_t n,
+                   uint64_t total_in, uint64_t total_out, uint64_t max_out, uint8_t *out,
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status);
+
+// deflate.hip
+size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item);
+int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
+                   size_t n, uint64_t total_in, uint64_t max_item, uint8_t *out,
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status);

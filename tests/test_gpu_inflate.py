@@ -1,0 +1,148 @@
+"""GPU inflate (raw / zlib / gzip) through the C ABI vs the oracle."""
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+import oracle_lib as o
+import rsx_pkg
+from golden.expand import expand
+
+pytestmark = pytest.mark.gpu
+
+WBITS = {0: -15, 1: 15, 2: 31}
+
+
+@pytest.fixture(scope="module")
+def rsx():
+    return rsx_pkg.load()
+
+
+@pytest.fixture(scope="module")
+def eng(rsx):
+    return rsx.default_engine()
+
+
+def check_against_oracle(eng, streams, caps, fmt):
+    got, status = eng.batch_decompress(streams, caps, fmt)
+    for i, s in enumerate(streams):
+        r, _, want = o.decompress(s, caps[i], fmt)
+        assert int(status[i]) == r, (i, int(status[i]), r)
+        if r == o.SUCCESS:
+            assert got[i] == want, i
+        else:
+            assert got[i] is None
+
+
+def test_reference_kat_streams(rsx, eng, kat):
+    streams = [bytes.fromhex(v["stream_hex"]) for v in kat["inflate"]]
+    wants = [expand(v["output"]) for v in kat["inflate"]]
+    got, status = eng.batch_decompress(streams, [len(w) for w in wants])
+    assert list(status) == [0, 0] and got == wants
+    bad = [bytes.fromhex(v["stream_hex"]) for v in kat["inflate_failures"]]
+    got, status = eng.batch_decompress(bad, [v["max_out"] for v in kat["inflate_failures"]])
+    assert got == [None]
+
+
+def test_batch_semantics_like_reference(rsx, kat):
+    # tests/batch_test.rs with streams produced by the oracle's level-6 compressor
+    inputs = [expand(d) for d in kat["batch_roundtrip_inputs"]]
+    comp = [o.compress(t, 6) for t in inputs]
+    dec = rsx.BatchDecompressor()
+    assert dec.decompress_batch(comp, [len(t) for t in inputs]) == inputs
+    assert dec.decompress_batch([], []) == []
+    v = kat["batch_empty_input"]
+    ins = [expand(d) for d in v["inputs"]]
+    comp = [o.compress(t, 6) for t in ins]
+    assert dec.decompress_batch(comp, v["max_out"]) == ins
+    v = kat["batch_insufficient"]
+    c = o.compress(expand(v["input"]), 6)
+    assert dec.decompress_batch([c], [v["max_out"]]) == [None]
+    assert dec.decompress_batch([bytes([0, 1, 2, 3, 4, 5])], [100]) == [None]
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_oracle_streams_all_levels(eng, fmt):
+    datas = [corpus.text(300000, 1), corpus.mixed(400000, 2), corpus.json_like(200000, 3),
+             bytes(100000), b"a", b"ab" * 5000, corpus.text(5000, 4)]
+    streams, caps = [], []
+    for lvl in (1, 2, 6, 9):
+        for d in datas:
+            streams.append(o.compress(d, lvl, fmt))
+            caps.append(len(d))
+    check_against_oracle(eng, streams, caps, fmt)
+
+
+def test_zlib_streams_including_stored_and_fixed(eng):
+    datas = [corpus.text(200000, 5), corpus.random_bytes(150000, 6), corpus.mixed(250000, 7)]
+    streams, caps = [], []
+    for d in datas:
+        for lvl in (0, 1, 6, 9):
+            streams.append(zlib.compress(d, lvl))
+            caps.append(len(d) + 100)
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+        streams.append(co.compress(d) + co.flush())
+        caps.append(len(d))
+    check_against_oracle(eng, streams, caps, 1)
+
+
+def test_overlapping_copies_every_small_offset(eng):
+    # tests/offset_tests.rs: period-N patterns force matches with offset < length
+    streams, caps = [], []
+    for period in list(range(1, 40)) + [63, 64, 65, 127, 258, 259, 1000]:
+        for n in (1000, 100000):
+            d = corpus.periodic(period, n)
+            for lvl in (6, 1):
+                c = o.compress(d, lvl)
+                if c is not None:  # a short incompressible pattern fails like the reference
+                    streams.append(c)
+                    caps.append(n)
+    check_against_oracle(eng, streams, caps, 0)
+
+
+def test_far_matches_and_window_edges(eng):
+    # matches at distance 32768 and around the LDS ring boundary
+    rs = np.random.RandomState(11)
+    block = rs.randint(0, 256, size=32768, dtype=np.uint8).tobytes()
+    d = block + block + block[:1000] + bytes(70000) + block
+    streams = [zlib.compress(d, 9)[2:-4], o.compress(d, 9)]
+    check_against_oracle(eng, streams, [len(d)] * 2, 0)
+
+
+def test_error_codes_match_oracle(eng):
+    t = corpus.text(50000, 8)
+    c = o.compress(t, 6)
+    g = o.compress(t, 6, 2)
+    z = o.compress(t, 6, 1)
+    bad_crc = bytearray(g); bad_crc[-6] ^= 1
+    bad_isize = bytearray(g); bad_isize[-1] ^= 1
+    bad_adler = bytearray(z); bad_adler[-1] ^= 1
+    cases = [
+        (c, len(t) - 1, 0), (c, 10, 0), (c[:len(c) // 2], len(t), 0), (c[:1], len(t), 0),
+        (b"", 10, 0), (b"\x07", 10, 0), (b"\x01\x05\x00\x00\x00", 10, 0),
+        (b"\x01\x05\x00\xfa\xffabc", 10, 0), (b"\x01\x05\x00\xfa\xffabcde", 4, 0),
+        (bytes([0x03, 0x02, 0x00, 0x00]), 100, 0),
+        (bytes(bad_crc), len(t), 2), (bytes(bad_isize), len(t), 2), (bytes(bad_adler), len(t), 1),
+        (b"\x78\x9d" + z[2:], len(t), 1), (z[:5], len(t), 1), (g[:17], len(t), 2),
+        (b"\x1f\x8b\x09" + g[3:], len(t), 2), (g, len(t) - 1, 2), (z, len(t) + 5, 1),
+    ]
+    rs = np.random.RandomState(5)
+    for k in range(40):  # random corruption of a valid stream
+        b = bytearray(c)
+        for _ in range(3):
+            b[rs.randint(0, len(b))] ^= 1 << rs.randint(0, 8)
+        cases.append((bytes(b), len(t), 0))
+    for fmt in (0, 1, 2):
+        sub = [(s, cap) for s, cap, f in cases if f == fmt]
+        if sub:
+            check_against_oracle(eng, [s for s, _ in sub], [cap for _, cap in sub], fmt)
+
+
+def test_gzip_header_fields(eng):
+    import gzip, io
+    t = corpus.text(20000, 9)
+    buf = io.BytesIO()
+    with gzip.GzipFile(filename="name.txt", mode="wb", fileobj=buf, mtime=0) as f:
+        f.write(t)
+    check_against_oracle(eng, [buf.getvalue()], [len(t)], 2)
