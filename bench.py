@@ -61,14 +61,15 @@ def cpu_baseline(streams, buf_bytes, fmt, target_s=12.0):
     in_off = np.zeros(d + 1, dtype=np.uint64)
     np.cumsum([len(s) for s in streams], out=in_off[1:])
     out_off = np.arange(d + 1, dtype=np.uint64) * np.uint64(buf_bytes)
+    orc.batch_decompress(flat, in_off, out_off, fmt, threads=th)  # warm-up
+    reps = 0
     t0 = time.perf_counter()
-    orc.batch_decompress(flat, in_off, out_off, fmt, threads=th)  # warm-up + rate estimate
-    once = time.perf_counter() - t0
-    reps = int(max(1, min(50, target_s / max(once, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    while True:
         _, sizes, status = orc.batch_decompress(flat, in_off, out_off, fmt, threads=th)
-    dt = time.perf_counter() - t0
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_s:
+            break
     assert (status == 0).all()
     nbytes = reps * (int(in_off[-1]) + int(sizes.sum()))
     return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": th, "kind": "port",

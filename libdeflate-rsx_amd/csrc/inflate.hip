@@ -7,15 +7,23 @@
 // framing (:1074-1240).  Result codes are the reference's DecompressResult.
 //
 // One 256-thread workgroup decodes one stream in rounds:
-//   1. stage   a 4 KiB window of compressed bytes into LDS with 16-byte
+//   1. stage   a ~4 KiB window of compressed bytes into LDS with 16-byte
 //              coalesced loads;
-//   2. decode  Huffman symbols from that window against decode tables held in
-//              LDS: literals go straight into a 32 KiB LDS ring that mirrors
-//              the tail of the output, matches are queued as (dst, len, dist);
+//   2. decode  all 256 lanes decode Huffman symbols at once.  The window is
+//              cut into 128-bit sub-sequences, lane i starts at a guessed bit
+//              position inside sub-sequence i and decodes until it crosses
+//              into sub-sequence i+1.  Huffman streams re-synchronise, so after
+//              a few passes of "restart where the previous lane really ended"
+//              every lane's start is the true one (lane 0 always is).  A prefix
+//              sum of the bytes each lane produces gives its output position,
+//              then each lane decodes once more and emits: literals straight
+//              into a 32 KiB LDS ring that mirrors the tail of the output,
+//              matches into a queue as (dst, len, dist);
 //   3. copy    all lanes resolve the queued matches in parallel -- a match may
 //              run once every byte below its source end is final; sources older
 //              than the ring are read back from the already written output;
 //   4. flush   the round's bytes leave the ring as 16-byte coalesced stores.
+// Block headers and decode tables are still handled by one lane.
 // HBM traffic is therefore one read of the compressed bytes and one write of
 // the output; the history window is served from LDS (and L2 for far matches).
 //
@@ -29,13 +37,24 @@ constexpr int kT = 256;                       // threads per stream
 constexpr int kRingBits = 15;
 constexpr uint32_t kRing = 1u << kRingBits;   // LDS mirror of the newest output bytes
 constexpr uint32_t kRingMask = kRing - 1;
-constexpr uint32_t kWinBytes = 4096;          // staged compressed bytes per round
+constexpr uint32_t kWinBytes = 4096 + 256;    // staged compressed bytes per round
 constexpr uint32_t kWinWords = kWinBytes / 4;
 // a token may start only while two dwords past its last fetch are still staged:
 // litlen fetch at b, offset fetch at most 20 bits later, each reads words w, w+1
 constexpr uint32_t kWinLimitBits = (kWinWords - 2) * 32 - 20;
-constexpr uint32_t kRoundOut = 8192;          // output bytes per round (<= kRing)
-constexpr uint32_t kMaxMatches = 768;         // match queue entries per round
+constexpr uint32_t kSubBits = 128;            // compressed bits per lane and round
+// one lane decodes at most kSubBits/2 matches of 258 bytes (a match token is
+// at least 2 bits), so a round that commits at least lane 0 always fits
+constexpr uint32_t kRoundOut = 20480;         // output bytes per round (<= kRing)
+constexpr uint32_t kMaxMatches = 2048;        // match queue entries per round
+static_assert(kSubBits / 2 * 258 <= kRoundOut && kSubBits / 2 <= kMaxMatches, "lane 0 must fit");
+static_assert(kRoundOut <= kRing, "a round may not lap the ring");
+
+// lane exit word: bit position (window relative) | flags
+constexpr uint32_t kExitEob = 1u << 31;       // the block ended in this lane
+constexpr uint32_t kExitStop = 1u << 30;      // ran out of input inside a token
+constexpr uint32_t kExitDead = 1u << 29;      // an earlier lane ended the block / input
+constexpr uint32_t kExitPosMask = (1u << 20) - 1;
 
 constexpr int kLitlenBits = 10;
 constexpr int kLitlenEnough = 1334;           // enough(288, 10, 15)
@@ -90,7 +109,11 @@ struct __align__(16) StreamLds {
     uint32_t litlen[kLitlenEnough];
     uint32_t offset[kOffsetEnough];
     uint32_t precode[kPrecodeEnough];
-    uint2 matches[kMaxMatches];   // x = (dst - round_start) | len << 16, y = dist
+    uint32_t match_dl[kMaxMatches];  // (dst - round_start) | len << 15
+    uint16_t match_dist[kMaxMatches];  // dist - 1
+    uint32_t lane_exit[kT];
+    uint32_t scan_carry[2 * (kT / 64)];
+    uint32_t emit_error;          // min over lanes of lane << 8 | DecompressResult
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
     uint8_t precode_lens[20];
@@ -103,6 +126,7 @@ struct __align__(16) StreamLds {
     int32_t in_block;     // 1 while inside a Huffman block body
     int32_t final_block;
     int32_t stored_len;   // >= 0: a stored block of that many bytes is pending
+    int32_t restage;      // header parse wants the window moved first
     uint64_t bitpos;      // next unread bit, relative to the start of the DEFLATE body
 };
 
@@ -232,28 +256,30 @@ __device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *w
     const uint8_t *cur = c.body + byte_pos;
     const uint8_t *wbase = cur - ((uintptr_t)cur & 15);
     *win_bit0 = ((int64_t)(wbase - c.body)) * 8;
-    const uint8_t *unit = wbase + 16 * threadIdx.x;   // kWinBytes / 16 == kT
     const uint8_t *body_end = c.body + c.body_len;
-    // the 16-byte unit is readable when it overlaps the allocation (an aligned
+    // a 16-byte unit is readable when it overlaps the allocation (an aligned
     // unit never crosses a page); bytes at or after the end of the body read as 0
     const uint8_t *alloc_lo = c.in_alloc - ((uintptr_t)c.in_alloc & 15);
     const uint8_t *alloc_hi = c.in_alloc + c.in_alloc_len;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (unit >= alloc_lo && unit < alloc_hi && unit < body_end) {
-        v = *reinterpret_cast<const uint4 *>(unit);
-        if (unit + 16 > body_end) {
-            uint32_t keep = (uint32_t)(body_end - unit);  // 1..15 valid bytes
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (uint32_t u = threadIdx.x; u < kWinBytes / 16; u += kT) {
+        const uint8_t *unit = wbase + 16 * (size_t)u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (unit >= alloc_lo && unit < alloc_hi && unit < body_end) {
+            v = *reinterpret_cast<const uint4 *>(unit);
+            if (unit + 16 > body_end) {
+                uint32_t keep = (uint32_t)(body_end - unit);  // 1..15 valid bytes
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int valid = (int)keep - 4 * k;  // bytes of this word that are valid
-                if (valid <= 0) w[k] = 0;
-                else if (valid < 4) w[k] &= (1u << (8 * valid)) - 1;
+                for (int k = 0; k < 4; k++) {
+                    int valid = (int)keep - 4 * k;  // bytes of this word that are valid
+                    if (valid <= 0) w[k] = 0;
+                    else if (valid < 4) w[k] &= (1u << (8 * valid)) - 1;
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        reinterpret_cast<uint4 *>(L.win)[u] = v;
     }
-    reinterpret_cast<uint4 *>(L.win)[threadIdx.x] = v;
     if (threadIdx.x < 2) L.win[kWinWords + threadIdx.x] = 0;
 }
 
@@ -341,134 +367,283 @@ __device__ __noinline__ void load_static_codes(StreamLds &L)
                        &L.litlen_tablebits);
 }
 
-// Thread-0 part of a round: block headers and symbol decoding from the staged
-// window.  Literals are stored into the ring, matches appended to the queue.
-// Order of the checks per symbol follows src/decompress/mod.rs:940-1071.
-__device__ __noinline__ void decode_round(StreamLds &L, const StreamCtx &c, int64_t win_bit0)
+// Thread-0 part of a round: when the stream is between blocks, read the next
+// block header from the staged window (src/decompress/mod.rs:225-252) and build
+// the decode tables.  Leaves L.in_block / L.stored_len / L.status / L.restage set.
+__device__ __noinline__ void header_step(StreamLds &L, const StreamCtx &c, int64_t win_bit0)
 {
     const uint64_t end_bit = c.body_len * 8;
     uint32_t b = (uint32_t)((int64_t)L.bitpos - win_bit0);
-    uint64_t out_pos = L.round_start_lo;
-    const uint64_t round_start = out_pos;
-    uint32_t nm = 0;
-    int status = -1;
-
-    while (status < 0 && b < kWinLimitBits && nm < kMaxMatches &&
-           out_pos + 258 <= round_start + kRoundOut) {
-        if (!L.in_block) {
-            // block header; needs the dynamic header fully staged: restart the
-            // round at this position unless the window has room for it
-            if (b + 8 * 640 > kWinLimitBits && b >= 128) break;
-            if ((uint64_t)(win_bit0 + b + 3) > end_bit) {
-                status = RSX_SHORT_INPUT;
-                break;
-            }
-            uint32_t bits = fetch_bits(L.win, b);
-            L.final_block = bits & 1;
-            uint32_t type = (bits >> 1) & 3;
-            b += 3;
-            if (type == 0) {
-                // stored block: byte-align, LEN / NLEN (src/decompress/mod.rs:282-304)
-                uint64_t abs = (uint64_t)(win_bit0 + b);
-                uint64_t byte = (abs + 7) >> 3;
-                if (byte + 4 > c.body_len) {
-                    status = RSX_SHORT_INPUT;
-                    break;
-                }
-                const uint8_t *p = c.body + byte;
-                uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
-                if (len != (~nlen & 0xFFFF)) {
-                    status = RSX_BAD_DATA;
-                    break;
-                }
-                L.stored_len = (int32_t)len;
-                L.bitpos = (byte + 4) * 8;
-                // the copy itself is done by the whole workgroup
-                L.num_matches = nm;
-                L.round_end_lo = (uint32_t)out_pos;
-                L.status = status;
-                return;
-            } else if (type == 3) {
-                status = RSX_BAD_DATA;
-                break;
-            } else if (type == 2) {
-                int r = read_dynamic_header(L, &b, win_bit0, end_bit);
-                if (r != RSX_SUCCESS) {
-                    status = r;
-                    break;
-                }
-            } else {
-                load_static_codes(L);
-            }
-            L.in_block = 1;
-            continue;
-        }
-
-        uint32_t bits = fetch_bits(L.win, b);
-        uint32_t e = L.litlen[bits & ((1u << L.litlen_tablebits) - 1)];
-        uint32_t used = 0;
-        if ((e & (kExceptional | kSubtable)) == (kExceptional | kSubtable)) {
-            used = e & 0xFF;
-            bits >>= used;
-            e = L.litlen[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
-        }
-        uint32_t total_bits = e & 0xFF;
-        if ((uint64_t)(win_bit0 + b + used + total_bits) > end_bit) {
-            status = RSX_SHORT_INPUT;
-            break;
-        }
-        b += used + total_bits;
-        if (e & kLiteral) {
-            if (out_pos >= c.out_cap) {
-                status = RSX_INSUFFICIENT_SPACE;
-                break;
-            }
-            L.ring[((uint32_t)out_pos + c.shift) & kRingMask] = (uint8_t)(e >> 16);
-            out_pos++;
-            continue;
-        }
-        if (e & kEndOfBlock) {
-            L.in_block = 0;
-            if (L.final_block) {
-                status = RSX_SUCCESS;
-                break;
-            }
-            continue;
-        }
-        uint32_t clen = (e >> 8) & 0xFF;
-        uint32_t length = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
-
-        bits = fetch_bits(L.win, b);
-        e = L.offset[bits & ((1u << kOffsetBits) - 1)];
-        used = 0;
-        if (e & kSubtable) {
-            used = e & 0xFF;
-            bits >>= used;
-            e = L.offset[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
-        }
-        total_bits = e & 0xFF;
-        if ((uint64_t)(win_bit0 + b + used + total_bits) > end_bit) {
-            status = RSX_SHORT_INPUT;
-            break;
-        }
-        b += used + total_bits;
-        clen = (e >> 8) & 0xFF;
-        uint32_t dist = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
-        if (dist > out_pos) {
-            status = RSX_BAD_DATA;
-            break;
-        }
-        if (out_pos + length > c.out_cap) {
-            status = RSX_INSUFFICIENT_SPACE;
-            break;
-        }
-        L.matches[nm++] = make_uint2((uint32_t)(out_pos - round_start) | (length << 16), dist);
-        out_pos += length;
+    L.restage = 0;
+    // a dynamic header is at most 14 + 19*3 + 320*14 bits; have it fully staged
+    if (b + 8 * 640 > kWinLimitBits && b >= 128) {
+        L.restage = 1;
+        return;
     }
+    if ((uint64_t)(win_bit0 + b + 3) > end_bit) {
+        L.status = RSX_SHORT_INPUT;
+        return;
+    }
+    uint32_t bits = fetch_bits(L.win, b);
+    L.final_block = bits & 1;
+    uint32_t type = (bits >> 1) & 3;
+    b += 3;
+    if (type == 0) {
+        // stored block: byte-align, LEN / NLEN (src/decompress/mod.rs:282-304)
+        uint64_t byte = ((uint64_t)(win_bit0 + b) + 7) >> 3;
+        if (byte + 4 > c.body_len) {
+            L.status = RSX_SHORT_INPUT;
+            return;
+        }
+        const uint8_t *p = c.body + byte;
+        uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
+        if (len != (~nlen & 0xFFFF)) {
+            L.status = RSX_BAD_DATA;
+            return;
+        }
+        L.stored_len = (int32_t)len;
+        L.bitpos = (byte + 4) * 8;
+        return;
+    }
+    if (type == 3) {
+        L.status = RSX_BAD_DATA;
+        return;
+    }
+    if (type == 2) {
+        int r = read_dynamic_header(L, &b, win_bit0, end_bit);
+        if (r != RSX_SUCCESS) {
+            L.status = r;
+            return;
+        }
+    } else {
+        load_static_codes(L);
+    }
+    L.in_block = 1;
     L.bitpos = (uint64_t)(win_bit0 + b);
-    L.num_matches = nm;
-    L.round_end_lo = (uint32_t)out_pos;
-    L.status = status;
+}
+
+// One decoded token.  kind: 0 literal, 1 match, 2 end of block.
+struct Token {
+    uint32_t nbits;  // bits consumed by the whole token
+    uint32_t kind;
+    uint32_t value;  // literal byte, or match length
+    uint32_t dist;
+};
+
+// Decode the token that starts at window bit b.  Bits past the end of the body
+// read as zero; the caller checks nbits against the bits really available.
+__device__ inline Token decode_token(const StreamLds &L, uint32_t b, uint32_t litlen_mask)
+{
+    Token t;
+    uint32_t bits = fetch_bits(L.win, b);
+    uint32_t e = L.litlen[bits & litlen_mask];
+    uint32_t used = 0;
+    if ((e & (kExceptional | kSubtable)) == (kExceptional | kSubtable)) {
+        used = e & 0xFF;
+        bits >>= used;
+        e = L.litlen[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
+    }
+    uint32_t total_bits = e & 0xFF;
+    used += total_bits;
+    t.nbits = used;
+    t.dist = 0;
+    if (e & kLiteral) {
+        t.kind = 0;
+        t.value = (e >> 16) & 0xFF;
+        return t;
+    }
+    if (e & kEndOfBlock) {
+        t.kind = 2;
+        t.value = 0;
+        return t;
+    }
+    uint32_t clen = (e >> 8) & 0xFF;
+    t.kind = 1;
+    t.value = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
+    bits = fetch_bits(L.win, b + used);
+    e = L.offset[bits & ((1u << kOffsetBits) - 1)];
+    if (e & kSubtable) {
+        uint32_t m = e & 0xFF;
+        used += m;
+        bits >>= m;
+        e = L.offset[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
+    }
+    total_bits = e & 0xFF;
+    clen = (e >> 8) & 0xFF;
+    t.dist = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
+    t.nbits = used + total_bits;
+    return t;
+}
+
+// What one lane learns from decoding its sub-sequence without emitting.
+struct Scan {
+    uint32_t exit;   // where the next lane starts (window bit) | kExit* flags
+    uint32_t bytes;  // output bytes of the tokens that start in [start, bound)
+    uint32_t nm;     // matches among them
+};
+
+// Decode tokens that start in [start, bound); end_b = first bit past the body.
+__device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bound, int64_t end_b,
+                                 uint32_t litlen_mask)
+{
+    Scan r{start, 0, 0};
+    uint32_t b = start;
+    while (b < bound) {
+        Token t = decode_token(L, b, litlen_mask);
+        if ((int64_t)(b + t.nbits) > end_b) {
+            r.exit = b | kExitStop;
+            return r;
+        }
+        b += t.nbits;
+        if (t.kind == 0) {
+            r.bytes += 1;
+        } else if (t.kind == 1) {
+            r.bytes += t.value;
+            r.nm += 1;
+        } else {
+            r.exit = b | kExitEob;
+            return r;
+        }
+    }
+    r.exit = b;
+    return r;
+}
+
+// exclusive prefix sums of two 32-bit values over the workgroup
+__device__ inline void wg_exclusive_scan2(StreamLds &L, uint32_t a, uint32_t b, uint32_t *ea,
+                                          uint32_t *eb)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t xa = a, xb = b;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t ya = __shfl_up(xa, o), yb = __shfl_up(xb, o);
+        if (lane >= o) {
+            xa += ya;
+            xb += yb;
+        }
+    }
+    if (lane == 63) {
+        L.scan_carry[2 * w] = xa;
+        L.scan_carry[2 * w + 1] = xb;
+    }
+    __syncthreads();
+    uint32_t ca = 0, cb = 0;
+    for (int k = 0; k < w; k++) {
+        ca += L.scan_carry[2 * k];
+        cb += L.scan_carry[2 * k + 1];
+    }
+    *ea = ca + xa - a;
+    *eb = cb + xb - b;
+    __syncthreads();
+}
+
+// All lanes: decode the Huffman block body in the staged window, starting at
+// L.bitpos.  On return literals are in the ring, matches in the queue and the
+// control block (bitpos, round_end, num_matches, in_block, status) is updated.
+// Order of the per-token checks follows src/decompress/mod.rs:940-1071.
+__device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t win_bit0)
+{
+    const int tid = threadIdx.x;
+    const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
+    const int64_t end_b = (int64_t)(c.body_len * 8) - win_bit0;  // first bit past the body
+    const uint32_t litlen_mask = (1u << L.litlen_tablebits) - 1;
+    const uint32_t round_start = L.round_start_lo;
+    // lane i owns tokens that start in [b0 + i*S, b0 + (i+1)*S), clipped to the window
+    const uint32_t lo = b0 + tid * kSubBits;
+    uint32_t bound = lo + kSubBits;
+    if (bound > kWinLimitBits) bound = kWinLimitBits;
+
+    // ---- passes 1..k: find every lane's true start ------------------------------
+    uint32_t start = lo;          // lane 0's guess is exact
+    Scan sc{0, 0, 0};
+    bool need = true;
+    // the true prefix grows by at least one lane per pass, so kT passes always suffice
+    for (int pass = 0; pass <= kT; pass++) {
+        if (need) {
+            if (start & kExitDead) {
+                sc = Scan{kExitDead, 0, 0};
+            } else if (start >= bound) {
+                sc = Scan{start, 0, 0};  // nothing starts here (window exhausted or overshoot)
+            } else {
+                sc = scan_span(L, start, bound, end_b, litlen_mask);
+            }
+            L.lane_exit[tid] = sc.exit;
+        }
+        __syncthreads();
+        uint32_t ns = lo;
+        if (tid > 0) {
+            uint32_t pe = L.lane_exit[tid - 1];
+            ns = (pe & (kExitEob | kExitStop | kExitDead)) ? kExitDead : pe;
+        }
+        need = ns != start;
+        start = ns;
+        if (!__syncthreads_or(need)) break;
+    }
+
+    // ---- output positions and the committed prefix ---------------------------------
+    uint32_t ex_bytes, ex_nm;
+    wg_exclusive_scan2(L, sc.bytes, sc.nm, &ex_bytes, &ex_nm);
+    const bool live = !(start & kExitDead);
+    const bool commit = live && ex_bytes + sc.bytes <= kRoundOut && ex_nm + sc.nm <= kMaxMatches;
+    // `commit` is monotone over lanes; the last committed lane publishes the round
+    L.lane_exit[tid] = commit ? sc.exit | 0x10000000u : sc.exit;
+    if (tid == 0) L.emit_error = ~0u;
+    __syncthreads();
+    const bool last = commit && (tid == kT - 1 || !(L.lane_exit[tid + 1] & 0x10000000u));
+
+    // ---- emit -------------------------------------------------------------------------
+    if (commit) {
+        uint32_t b = start;
+        uint64_t op = (uint64_t)round_start + ex_bytes;
+        uint32_t mi = ex_nm;
+        int err = -1;
+        while (b < bound) {
+            Token t = decode_token(L, b, litlen_mask);
+            if ((int64_t)(b + t.nbits) > end_b) {
+                err = RSX_SHORT_INPUT;
+                break;
+            }
+            b += t.nbits;
+            if (t.kind == 0) {
+                if (op >= c.out_cap) {
+                    err = RSX_INSUFFICIENT_SPACE;
+                    break;
+                }
+                L.ring[((uint32_t)op + c.shift) & kRingMask] = (uint8_t)t.value;
+                op++;
+            } else if (t.kind == 1) {
+                if (t.dist > op) {
+                    err = RSX_BAD_DATA;
+                    break;
+                }
+                if (op + t.value > c.out_cap) {
+                    err = RSX_INSUFFICIENT_SPACE;
+                    break;
+                }
+                L.match_dl[mi] = (uint32_t)(op - round_start) | (t.value << 15);
+                L.match_dist[mi] = (uint16_t)(t.dist - 1);
+                mi++;
+                op += t.value;
+            } else {
+                break;
+            }
+        }
+        if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
+    }
+    __syncthreads();
+    if (last) {
+        const uint32_t ee = L.emit_error;
+        L.bitpos = (uint64_t)(win_bit0 + (int64_t)(sc.exit & kExitPosMask));
+        L.round_end_lo = round_start + ex_bytes + sc.bytes;
+        L.num_matches = ex_nm + sc.nm;
+        if (ee != ~0u) {
+            L.status = (int32_t)(ee & 0xFF);  // the first failing token in stream order
+        } else if (sc.exit & kExitEob) {
+            L.in_block = 0;
+            if (L.final_block) L.status = RSX_SUCCESS;
+        }
+    }
+    __syncthreads();
 }
 
 // All lanes: resolve the queued matches of this round.
@@ -485,15 +660,16 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         const bool have = m < nm;
         uint32_t dst = 0, len = 0, dist = 1;
         if (have) {
-            uint2 q = L.matches[m];
-            dst = round_start + (q.x & 0xFFFF);
-            len = q.x >> 16;
-            dist = q.y;
+            uint32_t q = L.match_dl[m];
+            dst = round_start + (q & 0x7FFF);
+            len = q >> 15;
+            dist = (uint32_t)L.match_dist[m] + 1;
         }
         // all bytes below need_end must be final before this match may run
         const uint32_t need_end = dst - dist + (len < dist ? len : dist);
         bool done = !have;
-        for (;;) {
+        // the first unfinished match can always run, so kT passes always suffice
+        for (int pass = 0; pass <= kT; pass++) {
             unsigned long long open = __ballot(!done);
             if ((tid & 63) == 0)
                 L.first_open[tid >> 6] = open ? base + (tid & ~63) + (uint32_t)__builtin_ctzll(open) : ~0u;
@@ -502,7 +678,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (int w = 1; w < kT / 64; w++) f = f < L.first_open[w] ? f : L.first_open[w];
             if (f == ~0u) break;
             // every byte below the first unfinished match's destination is final
-            const uint32_t hw = round_start + (L.matches[f].x & 0xFFFF);
+            const uint32_t hw = round_start + (L.match_dl[f] & 0x7FFF);
             if (!done && need_end <= hw) {
                 for (uint32_t k = 0; k < len; k++) {
                     int64_t sp = (int64_t)dst + k - dist;
@@ -633,20 +809,56 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
         L.in_block = 0;
         L.final_block = 0;
         L.stored_len = -1;
+        L.restage = 0;
+        L.emit_error = ~0u;
         L.round_start_lo = 0;
         L.round_end_lo = 0;
         L.num_matches = 0;
     }
     uint32_t flushed = 0;  // output positions below this are in global memory (uniform)
+    uint64_t seen_bitpos = ~0ull;  // progress watchdog (uniform)
+    int stalled = 0;
     __syncthreads();
 
     for (;;) {
+        // every round either consumes input or moves the window; anything else is a bug
+        // and must not spin on the GPU
+        {
+            const uint64_t bp = L.bitpos;
+            stalled = bp == seen_bitpos ? stalled + 1 : 0;
+            seen_bitpos = bp;
+            __syncthreads();
+            if (stalled > 4) {
+                if (tid == 0) L.status = RSX_BAD_DATA;
+                __syncthreads();
+                break;
+            }
+        }
         int64_t win_bit0;
         stage_window(L, c, &win_bit0);
         __syncthreads();
-        if (tid == 0) decode_round(L, c, win_bit0);
-        __syncthreads();
-        copy_round(L, c);
+        if (!L.in_block) {
+            __syncthreads();
+            if (tid == 0) header_step(L, c, win_bit0);
+            __syncthreads();
+        }
+        {
+            // snapshot the control block, then let nobody change it before all have read it
+            const int restage = L.restage, st0 = L.status, stored0 = L.stored_len;
+            const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
+            __syncthreads();
+            if (restage) {  // the window has to move to the block header first
+                if (tid == 0) L.restage = 0;
+                continue;
+            }
+            if (st0 < 0 && stored0 < 0) {
+                // keep a whole sub-sequence plus one token inside the window
+                if (b0 + kSubBits + 64 > kWinLimitBits) continue;
+                decode_round_parallel(L, c, win_bit0);
+                // a failed round leaves holes in the match queue: nothing to copy
+                if (L.status < 0 || L.status == RSX_SUCCESS) copy_round(L, c);
+            }
+        }
         const uint32_t round_end = L.round_end_lo;
         int st = L.status;
         int32_t stored = L.stored_len;
