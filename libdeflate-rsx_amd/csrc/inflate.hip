@@ -31,6 +31,9 @@
 // compressed_len + uncompressed_len.
 #include "engine.h"
 
+#include <cstdlib>
+#include <vector>
+
 namespace {
 
 constexpr int kT = 256;                       // threads per stream
@@ -53,7 +56,6 @@ static_assert(kRoundOut <= kRing, "a round may not lap the ring");
 // lane exit word: bit position (window relative) | flags
 constexpr uint32_t kExitEob = 1u << 31;       // the block ended in this lane
 constexpr uint32_t kExitStop = 1u << 30;      // ran out of input inside a token
-constexpr uint32_t kExitDead = 1u << 29;      // an earlier lane ended the block / input
 constexpr uint32_t kExitPosMask = (1u << 20) - 1;
 
 constexpr int kLitlenBits = 10;
@@ -114,10 +116,13 @@ struct __align__(16) StreamLds {
     uint32_t lane_exit[kT];
     uint32_t scan_carry[2 * (kT / 64)];
     uint32_t emit_error;          // min over lanes of lane << 8 | DecompressResult
+    uint32_t stat_spec, stat_copy; // pass counters (STATS builds)
+    uint32_t first_flag;          // first lane whose sub-sequence ends the block / the input
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
     uint8_t precode_lens[20];
     uint32_t first_open[kT / 64];
+    uint32_t done_bits[kT / 32];  // finished matches of the current copy batch
     // control block written by thread 0, read by all after a barrier
     uint32_t litlen_tablebits;
     uint32_t num_matches;
@@ -430,12 +435,41 @@ struct Token {
     uint32_t dist;
 };
 
-// Decode the token that starts at window bit b.  Bits past the end of the body
+// Per-lane bit buffer over the staged window: at least 32 valid bits after
+// refill(), one LDS dword read per 32 consumed bits.
+struct BitReader {
+    uint64_t bb;     // unread bits, LSB first
+    uint32_t bc;     // valid bits in bb
+    uint32_t wnext;  // next window dword to load
+
+    __device__ inline void init(const StreamLds &L, uint32_t b)
+    {
+        const uint32_t w = b >> 5;
+        bb = (((uint64_t)L.win[w + 1] << 32) | L.win[w]) >> (b & 31);
+        bc = 64 - (b & 31);
+        wnext = w + 2;
+    }
+    __device__ inline void refill(const StreamLds &L)
+    {
+        if (bc < 32) {
+            bb |= (uint64_t)L.win[wnext++] << bc;
+            bc += 32;
+        }
+    }
+    __device__ inline void consume(uint32_t n)
+    {
+        bb >>= n;
+        bc -= n;
+    }
+};
+
+// Decode the token at the reader's position.  Bits past the end of the body
 // read as zero; the caller checks nbits against the bits really available.
-__device__ inline Token decode_token(const StreamLds &L, uint32_t b, uint32_t litlen_mask)
+__device__ inline Token decode_token(const StreamLds &L, BitReader &r, uint32_t litlen_mask)
 {
     Token t;
-    uint32_t bits = fetch_bits(L.win, b);
+    r.refill(L);
+    uint32_t bits = (uint32_t)r.bb;
     uint32_t e = L.litlen[bits & litlen_mask];
     uint32_t used = 0;
     if ((e & (kExceptional | kSubtable)) == (kExceptional | kSubtable)) {
@@ -445,6 +479,7 @@ __device__ inline Token decode_token(const StreamLds &L, uint32_t b, uint32_t li
     }
     uint32_t total_bits = e & 0xFF;
     used += total_bits;
+    r.consume(used);
     t.nbits = used;
     t.dist = 0;
     if (e & kLiteral) {
@@ -460,18 +495,21 @@ __device__ inline Token decode_token(const StreamLds &L, uint32_t b, uint32_t li
     uint32_t clen = (e >> 8) & 0xFF;
     t.kind = 1;
     t.value = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
-    bits = fetch_bits(L.win, b + used);
+    r.refill(L);
+    bits = (uint32_t)r.bb;
     e = L.offset[bits & ((1u << kOffsetBits) - 1)];
+    used = 0;
     if (e & kSubtable) {
-        uint32_t m = e & 0xFF;
-        used += m;
-        bits >>= m;
+        used = e & 0xFF;
+        bits >>= used;
         e = L.offset[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
     }
     total_bits = e & 0xFF;
     clen = (e >> 8) & 0xFF;
     t.dist = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
-    t.nbits = used + total_bits;
+    used += total_bits;
+    r.consume(used);
+    t.nbits += used;
     return t;
 }
 
@@ -488,8 +526,10 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
 {
     Scan r{start, 0, 0};
     uint32_t b = start;
+    BitReader br;
+    br.init(L, b);
     while (b < bound) {
-        Token t = decode_token(L, b, litlen_mask);
+        Token t = decode_token(L, br, litlen_mask);
         if ((int64_t)(b + t.nbits) > end_b) {
             r.exit = b | kExitStop;
             return r;
@@ -554,15 +594,16 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     if (bound > kWinLimitBits) bound = kWinLimitBits;
 
     // ---- passes 1..k: find every lane's true start ------------------------------
+    // A lane that decodes an end-of-block (or runs out of input) while its start is
+    // still a guess must not silence the lanes behind it: they keep their own guess
+    // until the chain in front of them is settled.
     uint32_t start = lo;          // lane 0's guess is exact
     Scan sc{0, 0, 0};
     bool need = true;
     // the true prefix grows by at least one lane per pass, so kT passes always suffice
     for (int pass = 0; pass <= kT; pass++) {
         if (need) {
-            if (start & kExitDead) {
-                sc = Scan{kExitDead, 0, 0};
-            } else if (start >= bound) {
+            if (start >= bound) {
                 sc = Scan{start, 0, 0};  // nothing starts here (window exhausted or overshoot)
             } else {
                 sc = scan_span(L, start, bound, end_b, litlen_mask);
@@ -573,21 +614,34 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         uint32_t ns = lo;
         if (tid > 0) {
             uint32_t pe = L.lane_exit[tid - 1];
-            ns = (pe & (kExitEob | kExitStop | kExitDead)) ? kExitDead : pe;
+            if (!(pe & (kExitEob | kExitStop))) ns = pe;
         }
         need = ns != start;
         start = ns;
+        if (tid == 0) L.stat_spec++;
         if (!__syncthreads_or(need)) break;
+    }
+    // every start now follows from lane 0's: the first lane that ended the block
+    // (or the input) is real, and nothing behind it belongs to this block
+    if (tid == 0) {
+        L.first_flag = kT;
+        L.emit_error = ~0u;
+    }
+    __syncthreads();
+    if (sc.exit & (kExitEob | kExitStop)) atomicMin(&L.first_flag, (uint32_t)tid);
+    __syncthreads();
+    const bool live = (uint32_t)tid <= L.first_flag;
+    if (!live) {
+        sc.bytes = 0;
+        sc.nm = 0;
     }
 
     // ---- output positions and the committed prefix ---------------------------------
     uint32_t ex_bytes, ex_nm;
     wg_exclusive_scan2(L, sc.bytes, sc.nm, &ex_bytes, &ex_nm);
-    const bool live = !(start & kExitDead);
     const bool commit = live && ex_bytes + sc.bytes <= kRoundOut && ex_nm + sc.nm <= kMaxMatches;
     // `commit` is monotone over lanes; the last committed lane publishes the round
     L.lane_exit[tid] = commit ? sc.exit | 0x10000000u : sc.exit;
-    if (tid == 0) L.emit_error = ~0u;
     __syncthreads();
     const bool last = commit && (tid == kT - 1 || !(L.lane_exit[tid + 1] & 0x10000000u));
 
@@ -597,8 +651,10 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         uint64_t op = (uint64_t)round_start + ex_bytes;
         uint32_t mi = ex_nm;
         int err = -1;
+        BitReader br;
+        br.init(L, b);
         while (b < bound) {
-            Token t = decode_token(L, b, litlen_mask);
+            Token t = decode_token(L, br, litlen_mask);
             if ((int64_t)(b + t.nbits) > end_b) {
                 err = RSX_SHORT_INPUT;
                 break;
@@ -646,7 +702,11 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     __syncthreads();
 }
 
-// All lanes: resolve the queued matches of this round.
+// All lanes: resolve the queued matches of this round, kT at a time.  Inside a
+// batch a match waits only for the earlier matches whose destination overlaps its
+// source bytes (found by binary search in the queue, which is sorted by
+// destination); everything older is final.  Passes per batch = depth of the
+// dependency chain, not the number of near matches.
 __device__ void copy_round(StreamLds &L, const StreamCtx &c)
 {
     const uint32_t nm = L.num_matches;
@@ -659,36 +719,92 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         const uint32_t m = base + tid;
         const bool have = m < nm;
         uint32_t dst = 0, len = 0, dist = 1;
+        uint32_t dep_a = 0, dep_b = 0;  // batch-relative range of matches my source overlaps
+        if (tid < kT / 32) L.done_bits[tid] = 0;
         if (have) {
             uint32_t q = L.match_dl[m];
-            dst = round_start + (q & 0x7FFF);
+            const uint32_t drel = q & 0x7FFF;
+            dst = round_start + drel;
             len = q >> 15;
             dist = (uint32_t)L.match_dist[m] + 1;
-        }
-        // all bytes below need_end must be final before this match may run
-        const uint32_t need_end = dst - dist + (len < dist ? len : dist);
-        bool done = !have;
-        // the first unfinished match can always run, so kT passes always suffice
-        for (int pass = 0; pass <= kT; pass++) {
-            unsigned long long open = __ballot(!done);
-            if ((tid & 63) == 0)
-                L.first_open[tid >> 6] = open ? base + (tid & ~63) + (uint32_t)__builtin_ctzll(open) : ~0u;
-            __syncthreads();
-            uint32_t f = L.first_open[0];
-            for (int w = 1; w < kT / 64; w++) f = f < L.first_open[w] ? f : L.first_open[w];
-            if (f == ~0u) break;
-            // every byte below the first unfinished match's destination is final
-            const uint32_t hw = round_start + (L.match_dl[f] & 0x7FFF);
-            if (!done && need_end <= hw) {
-                for (uint32_t k = 0; k < len; k++) {
-                    int64_t sp = (int64_t)dst + k - dist;
-                    uint8_t v = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask]
-                                             : c.out[sp];
-                    L.ring[(dst + k + c.shift) & kRingMask] = v;
+            // source bytes [s, s_end) relative to round_start (s may lie before the round)
+            const int32_t s = (int32_t)drel - (int32_t)dist;
+            const int32_t s_end = s + (int32_t)(len < dist ? len : dist);
+            if (s_end > 0) {
+                // first match in [base, m) whose end is behind s
+                uint32_t lo = base, hi = m;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    uint32_t qq = L.match_dl[mid];
+                    if ((int32_t)((qq & 0x7FFF) + (qq >> 15)) > s) hi = mid; else lo = mid + 1;
                 }
-                done = true;
+                dep_a = lo - base;
+                uint32_t j = lo;
+                while (j < m && (int32_t)(L.match_dl[j] & 0x7FFF) < s_end) j++;
+                dep_b = j - base;
             }
-            __syncthreads();
+        }
+        bool done = !have, published = !have;
+        __syncthreads();
+        // the first unfinished match of a batch can always run, so kT passes suffice
+        for (int pass = 0; pass <= kT; pass++) {
+            if (!done) {
+                bool ready = true;
+                for (uint32_t j = dep_a; j < dep_b; j++)
+                    if (!((L.done_bits[j >> 5] >> (j & 31)) & 1)) {
+                        ready = false;
+                        break;
+                    }
+                if (ready) {
+                    const uint32_t d0 = dst + c.shift, s0 = d0 - dist;
+                    if ((int64_t)dst - dist < lds_lo) {
+                        // far source: part of it has left the ring, read that from the output
+                        for (uint32_t k = 0; k < len; k++) {
+                            int64_t sp = (int64_t)dst + k - dist;
+                            uint8_t v = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask]
+                                                     : c.out[sp];
+                            L.ring[(d0 + k) & kRingMask] = v;
+                        }
+                    } else if (dist >= 8) {
+                        // 8 independent loads, then 8 stores: one LDS round trip per 8 bytes
+                        uint32_t k = 0;
+                        for (; k + 8 <= len; k += 8) {
+                            uint8_t v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) v[j] = L.ring[(s0 + k + j) & kRingMask];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) L.ring[(d0 + k + j) & kRingMask] = v[j];
+                        }
+                        uint8_t v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (k + j < len) v[j] = L.ring[(s0 + k + j) & kRingMask];
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (k + j < len) L.ring[(d0 + k + j) & kRingMask] = v[j];
+                    } else {
+                        // overlapping copy: the output repeats the last `dist` bytes
+                        uint64_t pat = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < 7; j++)
+                            if (j < dist) pat |= (uint64_t)L.ring[(s0 + j) & kRingMask] << (8 * j);
+                        uint32_t idx = 0;
+                        for (uint32_t k = 0; k < len; k++) {
+                            L.ring[(d0 + k) & kRingMask] = (uint8_t)(pat >> (8 * idx));
+                            idx = idx + 1 == dist ? 0 : idx + 1;
+                        }
+                    }
+                    done = true;
+                    dep_a = dep_b = 0;
+                }
+            }
+            if (tid == 0) L.stat_copy++;
+            __syncthreads();  // copies of this pass are visible before their done bits
+            if (done && !published) {
+                atomicOr(&L.done_bits[tid >> 5], 1u << (tid & 31));
+                published = true;
+            }
+            if (!__syncthreads_or(!done)) break;
         }
         __syncthreads();
     }
@@ -771,11 +887,19 @@ __device__ ContainerInfo parse_container(int format, const uint8_t *in, uint64_t
     return ci;
 }
 
+// STATS builds add per-stream phase timers (development aid, RSX_INFLATE_STATS=1):
+// stats[item*8 + k]: 0 rounds, 1 speculation passes, 2 copy passes, 3..7 cycles in
+// stage / header / decode / copy / flush
+template <bool STATS>
 __global__ __launch_bounds__(kT) void inflate_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
-    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end)
+    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
+    unsigned long long *__restrict__ stats)
 {
+    unsigned long long tS = 0, tH = 0, tD = 0, tC = 0, tF = 0, t0 = 0, nRounds = 0;
+#define STAT_BEGIN() do { if (STATS) t0 = clock64(); } while (0)
+#define STAT_END(acc) do { if (STATS) acc += clock64() - t0; } while (0)
     __shared__ StreamLds L;
     const uint32_t item = blockIdx.x;
     if (item >= n) return;
@@ -811,6 +935,8 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
         L.stored_len = -1;
         L.restage = 0;
         L.emit_error = ~0u;
+        L.stat_spec = 0;
+        L.stat_copy = 0;
         L.round_start_lo = 0;
         L.round_end_lo = 0;
         L.num_matches = 0;
@@ -835,12 +961,17 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
             }
         }
         int64_t win_bit0;
+        STAT_BEGIN();
         stage_window(L, c, &win_bit0);
         __syncthreads();
+        STAT_END(tS);
+        nRounds++;
         if (!L.in_block) {
+            STAT_BEGIN();
             __syncthreads();
             if (tid == 0) header_step(L, c, win_bit0);
             __syncthreads();
+            STAT_END(tH);
         }
         {
             // snapshot the control block, then let nobody change it before all have read it
@@ -854,9 +985,13 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
             if (st0 < 0 && stored0 < 0) {
                 // keep a whole sub-sequence plus one token inside the window
                 if (b0 + kSubBits + 64 > kWinLimitBits) continue;
+                STAT_BEGIN();
                 decode_round_parallel(L, c, win_bit0);
+                STAT_END(tD);
                 // a failed round leaves holes in the match queue: nothing to copy
+                STAT_BEGIN();
                 if (L.status < 0 || L.status == RSX_SUCCESS) copy_round(L, c);
+                STAT_END(tC);
             }
         }
         const uint32_t round_end = L.round_end_lo;
@@ -910,6 +1045,7 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
             continue;
         }
         if (st >= 0) break;
+        STAT_BEGIN();
         uint32_t upto = ((round_end + c.shift) & ~15u);
         upto = upto > c.shift ? upto - c.shift : 0;
         if (upto < flushed) upto = flushed;
@@ -917,6 +1053,7 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
         flushed = upto;
         if (tid == 0) L.round_start_lo = round_end;
         __syncthreads();
+        STAT_END(tF);
     }
 
     const int st = L.status;
@@ -927,7 +1064,14 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
         out_sizes[item] = st == RSX_SUCCESS ? produced : 0;
         // first byte behind the DEFLATE stream, relative to the item start
         body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
+        if (STATS) {
+            unsigned long long *q = stats + (size_t)item * 8;
+            q[0] = nRounds; q[1] = L.stat_spec; q[2] = L.stat_copy;
+            q[3] = tS; q[4] = tH; q[5] = tD; q[6] = tC; q[7] = tF;
+        }
     }
+#undef STAT_BEGIN
+#undef STAT_END
 }
 
 // zlib / gzip trailer check (src/decompress/mod.rs:1104-1120, :1202-1233): the
@@ -979,10 +1123,33 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         e->err = "workspace exhausted";
         return RSX_E_NOMEM;
     }
+    const bool want_stats = getenv("RSX_INFLATE_STATS") != nullptr;
+    unsigned long long *d_stats = nullptr;
+    if (want_stats) {
+        RSX_HIP(e, hipMalloc(&d_stats, n * 8 * sizeof(unsigned long long)));
+    }
     (void)hipEventRecord(e->ev_begin, e->stream);
-    inflate_kernel<<<(uint32_t)n, kT, 0, e->stream>>>(format, in, in_off, (uint32_t)n, total_in, out,
-                                                      out_off, out_sizes, status, body_end);
+    if (want_stats)
+        inflate_kernel<true><<<(uint32_t)n, kT, 0, e->stream>>>(
+            format, in, in_off, (uint32_t)n, total_in, out, out_off, out_sizes, status, body_end, d_stats);
+    else
+        inflate_kernel<false><<<(uint32_t)n, kT, 0, e->stream>>>(
+            format, in, in_off, (uint32_t)n, total_in, out, out_off, out_sizes, status, body_end, nullptr);
     (void)hipEventRecord(e->ev_end, e->stream);
+    if (want_stats) {
+        std::vector<unsigned long long> h(n * 8);
+        RSX_HIP(e, hipMemcpy(h.data(), d_stats, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_stats);
+        unsigned long long sum[8] = {0};
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 8; k++) sum[k] += h[i * 8 + k];
+        fprintf(stderr,
+                "[rsx inflate stats] streams %zu rounds %.1f spec_passes/round %.2f copy_passes/round %.2f "
+                "cycles/stream: stage %.0f header %.0f decode %.0f copy %.0f flush %.0f\n",
+                n, (double)sum[0] / n, (double)sum[1] / (double)sum[0], (double)sum[2] / (double)sum[0],
+                (double)sum[3] / n, (double)sum[4] / n, (double)sum[5] / n, (double)sum[6] / n,
+                (double)sum[7] / n);
+    }
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
     if (format != RSX_FORMAT_DEFLATE) {
