@@ -1,0 +1,129 @@
+"""GPU deflate (raw / zlib / gzip) through the C ABI: every stream must be valid for
+its format and inflate -- with the oracle, with zlib and with the GPU inflater --
+to exactly the input; sizes stay close to the oracle's at the same level."""
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+import oracle_lib as o
+import rsx_pkg
+from golden.expand import expand
+
+pytestmark = pytest.mark.gpu
+
+WBITS = {0: -15, 1: 15, 2: 31}
+
+
+@pytest.fixture(scope="module")
+def rsx():
+    return rsx_pkg.load()
+
+
+@pytest.fixture(scope="module")
+def eng(rsx):
+    return rsx.default_engine()
+
+
+def roundtrip(eng, datas, fmt, level):
+    comp, status = eng.batch_compress(datas, fmt, level)
+    assert list(status) == [0] * len(datas), list(status)
+    for d, c in zip(datas, comp):
+        assert len(c) <= o.compress_bound(fmt, len(d))
+        assert zlib.decompress(c, WBITS[fmt]) == d
+        assert o.decompress(c, len(d), fmt) == (o.SUCCESS, len(c), d)
+    back, st = eng.batch_decompress(comp, [len(d) for d in datas], fmt)
+    assert list(st) == [0] * len(datas) and back == list(datas)
+    return comp
+
+
+def test_reference_batch_tests(rsx, kat):
+    # tests/batch_test.rs through the mirrored API
+    inputs = [expand(d) for d in kat["batch_roundtrip_inputs"]]
+    comp = rsx.BatchCompressor(6).compress_batch(inputs)
+    assert len(comp) == len(inputs) and all(len(c) > 0 for c in comp)
+    assert rsx.BatchDecompressor().decompress_batch(comp, [len(t) for t in inputs]) == inputs
+    assert rsx.BatchCompressor(6).compress_batch([]) == []
+    v = kat["batch_empty_input"]
+    ins = [expand(d) for d in v["inputs"]]
+    comp = rsx.BatchCompressor(6).compress_batch(ins)
+    assert len(comp[0]) > 0
+    assert rsx.BatchDecompressor().decompress_batch(comp, v["max_out"]) == ins
+    v = kat["batch_insufficient"]
+    comp = rsx.BatchCompressor(6).compress_batch([expand(v["input"])])
+    assert rsx.BatchDecompressor().decompress_batch(comp, [v["max_out"]]) == [None]
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9, 12])
+def test_roundtrip_formats_levels(eng, fmt, level):
+    datas = [corpus.text(300000, 1), corpus.mixed(400000, 2), corpus.json_like(100000, 3), b"",
+             b"a", b"abc", b"ab" * 3000, bytes(70000), corpus.random_bytes(5000, 4),
+             corpus.text(262144, 5), corpus.text(262145, 6), corpus.text(511, 7),
+             corpus.text(512, 8), corpus.text(513, 9), corpus.text(1025, 10)]
+    roundtrip(eng, datas, fmt, level)
+
+
+def test_parallel_test_shapes(eng):
+    # tests/parallel_test.rs: inputs that exercise the >256 KiB chunked path
+    datas = [bytes(i % 256 for i in range(1 << 20)), bytes(i % 256 for i in range(256 * 1024 + 1)),
+             bytes((i * 3) % 251 for i in range(600000)), bytes((i * 7) % 251 for i in range(600000))]
+    comp = roundtrip(eng, datas, 0, 6)
+    assert comp[0].count(b"\x00\x00\xff\xff") >= 3  # sync-flush joints between the four chunks
+    roundtrip(eng, datas[2:], 1, 6)
+    roundtrip(eng, datas[2:], 2, 6)
+
+
+def test_periodic_patterns(eng):
+    # tests/offset_tests.rs shapes
+    datas = [corpus.periodic(p, n) for p in list(range(1, 34)) + [63, 64, 65, 258, 259, 1000]
+             for n in (1000, 100000)]
+    roundtrip(eng, datas, 0, 6)
+    roundtrip(eng, datas[::5], 0, 1)
+
+
+def test_incompressible_uses_stored_blocks(eng):
+    # the reference fails here (no stored fallback, src/compress/mod.rs:1475-1496); the
+    # engine emits stored blocks and fits the bound
+    d = corpus.random_bytes(65536, 12)
+    assert o.compress(d, 6) is None
+    comp = roundtrip(eng, [d, corpus.random_bytes(200000, 13)], 0, 6)
+    assert len(comp[0]) <= len(d) + 16
+
+
+def test_level_ordering_and_ratio_vs_oracle(eng):
+    # tests/unit_tests.rs:112-125: L0 > L1 >= L12 on 10000 x 'a'
+    d = b"a" * 10000
+    sizes = {lvl: len(eng.batch_compress([d], 0, lvl)[0][0]) for lvl in (0, 1, 6, 12)}
+    assert sizes[0] > sizes[1] >= sizes[12]
+    t = [corpus.text(1 << 20, s) for s in range(4)] + [corpus.mixed(1 << 20, 7)]
+    comp, _ = eng.batch_compress(t, 0, 6)
+    for d, c in zip(t, comp):
+        ref = o.compress(d, 6)
+        assert len(c) <= 1.06 * len(ref), (len(c), len(ref))
+
+
+def test_api_surface(rsx):
+    c = rsx.Compressor(6)
+    d = corpus.text(50000, 3)
+    for comp, dec in ((c.compress_deflate, "decompress_deflate"), (c.compress_zlib, "decompress_zlib"),
+                      (c.compress_gzip, "decompress_gzip")):
+        z = comp(d)
+        assert getattr(rsx.Decompressor(), dec)(z, len(d)) == d
+    with pytest.raises(ValueError, match="Compression level must be between 0 and 12"):
+        rsx.Compressor(13)
+    buf = bytearray(10)
+    with pytest.raises(RuntimeError, match="Insufficient space"):
+        c.compress_deflate_into(d, buf)
+    with pytest.raises(RuntimeError, match="Compression failed"):
+        c.compress_zlib_into(d, buf)
+    dd = rsx.Decompressor()
+    with pytest.raises(ValueError, match="exceeds safety limit"):
+        dd.decompress_deflate(b"\x03\x00", 10**9)   # tests/security_limit.rs
+    dd.set_max_memory_limit(100)
+    with pytest.raises(ValueError, match="exceeds maximum memory limit"):
+        dd.decompress_deflate(c.compress_deflate(d), len(d))
+    with pytest.raises(RuntimeError, match="Decompression failed"):
+        rsx.Decompressor().decompress_deflate(b"\x00\x01\x02\x03\x04\x05", 100)
+    assert c.deflate_compress_bound(65536) == 65556 and c.gzip_compress_bound(0) == 33
