@@ -77,6 +77,110 @@ def cpu_baseline(streams, buf_bytes, fmt, target_s=12.0):
                       % (reps, d, reps, dt)}
 
 
+def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
+    """BASELINE.json configs[2]: batch zlib compress level 6, n x 1 MiB mixed text/binary."""
+    import corpus
+    import oracle_lib as orc
+    fmt, level = rsx.FORMAT_ZLIB, 6
+    buf = args.buf_kib * 1024
+    n = args.streams
+    distinct = min(args.distinct, n)
+    datas = [corpus.mixed(buf, 1000 * rank + i) for i in range(distinct)]
+    h_in = np.frombuffer(b"".join(datas), dtype=np.uint8)
+    d_one = torch.from_numpy(h_in.copy()).to(dev)
+    d_in = d_one.repeat(n // distinct + 1)[: n * buf].contiguous()  # private copy per item
+    in_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)
+    bound = int(rsx.compress_bound(fmt, buf))
+    out_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(bound)
+    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
+    d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
+    d_out = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    eng = rsx.Engine(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    total_in = n * buf
+
+    def step():
+        eng.batch_compress_device(fmt, level, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, buf,
+                                  d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                  d_status.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = []
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(eng.last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    st = d_status.cpu().numpy()
+    sz = d_sizes.cpu().numpy()
+    ok = bool((st == 0).all())
+    for i in range(distinct):  # the oracle must inflate every distinct stream to its input
+        c = d_out[i * bound: i * bound + int(sz[i])].cpu().numpy().tobytes()
+        r, _, back = orc.decompress(c, buf, orc.FMT_ZLIB)
+        ok = ok and r == 0 and back == datas[i]
+    if not ok:
+        raise SystemExit("bench.py: compressed output failed verification")
+    total_out = int(sz.sum())
+    job_bytes = total_in + total_out
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        b = torch.tensor([job_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        job_bytes = int(b.item())
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        achieved = (total_in + total_out) / (k_ms * 1e-3) / 1e9
+        res = {
+            "metric": "batch GiB/s in+out (compress@L6, decompress) at 1/2/4/8 GPUs; % HBM roofline",
+            "value": job_bytes * args.steps / dt / 2**30, "unit": "GiB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "batch zlib compress level 6, %d x %d KiB mixed text/binary per GPU"
+                                   % (n, args.buf_kib),
+                       "op": "compress", "format": "zlib", "level": level, "streams_per_gpu": n,
+                       "buf_bytes": buf, "distinct_buffers": distinct,
+                       "compressed_ratio": total_in / total_out, "verified": ok},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "deflate_chunks_kernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes": total_in + total_out},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            th = host_threads()
+            flat = np.frombuffer(b"".join(datas), dtype=np.uint8)
+            off = np.arange(distinct + 1, dtype=np.uint64) * np.uint64(buf)
+            t1 = time.perf_counter()
+            reps = 0
+            while True:
+                _, _, csz, cst = orc.batch_compress(flat, off, orc.FMT_ZLIB, level, threads=th)
+                reps += 1
+                cdt = time.perf_counter() - t1
+                if cdt >= 12.0:
+                    break
+            res["cpu_baseline"] = {"value": reps * (distinct * buf + int(csz.sum())) / cdt / 2**30,
+                                   "unit": "GiB/s", "cores": th, "kind": "port",
+                                   "sample": "%d passes over %d distinct buffers, %.1f s" % (reps, distinct, cdt),
+                                   "compressed_ratio": distinct * buf / float(csz.sum())}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +190,8 @@ def main():
     ap.add_argument("--buf-kib", type=int, default=1024, help="uncompressed KiB per stream")
     ap.add_argument("--distinct", type=int, default=64, help="distinct buffers generated on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op", choices=["decompress", "compress"], default="decompress",
+                    help="decompress = gzip level-6 text (headline); compress = zlib level-6 mixed")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +209,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.op == "compress":
+        return bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev)
     fmt, level = rsx.FORMAT_GZIP, 6
     buf = args.buf_kib * 1024
     n = args.streams
