@@ -34,10 +34,15 @@
 #include <cstdlib>
 #include <vector>
 
+// build with -DRSX_DEV_TIMERS=1 to get the finer in-kernel timers of RSX_INFLATE_STATS
+#ifndef RSX_DEV_TIMERS
+#define RSX_DEV_TIMERS 0
+#endif
+
 namespace {
 
 constexpr int kT = 256;                       // threads per stream
-constexpr int kRingBits = 15;
+constexpr int kRingBits = 14;
 constexpr uint32_t kRing = 1u << kRingBits;   // LDS mirror of the newest output bytes
 constexpr uint32_t kRingMask = kRing - 1;
 constexpr uint32_t kWinBytes = 4096 + 256;    // staged compressed bytes per round
@@ -45,13 +50,17 @@ constexpr uint32_t kWinWords = kWinBytes / 4;
 // a token may start only while two dwords past its last fetch are still staged:
 // litlen fetch at b, offset fetch at most 20 bits later, each reads words w, w+1
 constexpr uint32_t kWinLimitBits = (kWinWords - 2) * 32 - 20;
-constexpr uint32_t kSubBits = 128;            // compressed bits per lane and round
+constexpr uint32_t kSubBits = 120;            // compressed bits per lane and round
 // one lane decodes at most kSubBits/2 matches of 258 bytes (a match token is
 // at least 2 bits), so a round that commits at least lane 0 always fits
-constexpr uint32_t kRoundOut = 20480;         // output bytes per round (<= kRing)
-constexpr uint32_t kMaxMatches = 2048;        // match queue entries per round
+constexpr uint32_t kRoundOut = 16384 - 16;    // output bytes per round
+constexpr uint32_t kMaxMatches = 1536;        // match queue entries per round
+constexpr uint32_t kCopySub = 2048;           // output bytes resolved per copy step (u16 pointers fit in win)
+static_assert(kCopySub * 2 <= kWinBytes, "copy pointers live in the window buffer");
 static_assert(kSubBits / 2 * 258 <= kRoundOut && kSubBits / 2 <= kMaxMatches, "lane 0 must fit");
-static_assert(kRoundOut <= kRing, "a round may not lap the ring");
+// up to 15 bytes of a round stay unflushed (16-byte store granularity): the next round
+// must not overwrite them in the ring
+static_assert(kRoundOut + 16 <= kRing, "a round may not lap the unflushed tail in the ring");
 
 // lane exit word: bit position (window relative) | flags
 constexpr uint32_t kExitEob = 1u << 31;       // the block ended in this lane
@@ -104,26 +113,41 @@ __device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t len)
     return decode_result(kind, sym) + (len << 8) + len;
 }
 
-// Everything a workgroup keeps in LDS.
+// Everything a workgroup keeps in LDS.  Three groups of arrays are never live at
+// the same time and share storage: header parsing scratch, the per-sub-sequence
+// bookkeeping of the speculation passes, and the match queue.
+struct HeaderScratch {
+    uint32_t precode[kPrecodeEnough];
+    uint16_t sorted_syms[288];
+    uint8_t lens[288 + 32 + 140];
+    uint8_t precode_lens[20];
+};
+struct SpecScratch {
+    uint32_t sub_start[kT];       // start handed to a sub-sequence that is re-decoded
+    uint16_t sub_bytes[kT], sub_nm[kT];
+    uint16_t work[kT];            // compacted list of sub-sequences to re-decode
+};
+struct MatchQueue {
+    uint32_t dl[kMaxMatches];     // (dst - round_start) | len << 15
+    uint16_t dist[kMaxMatches];   // dist - 1
+};
 struct __align__(16) StreamLds {
     uint8_t ring[kRing];
-    uint32_t win[kWinWords + 2];
-    uint32_t litlen[kLitlenEnough];
-    uint32_t offset[kOffsetEnough];
-    uint32_t precode[kPrecodeEnough];
-    uint32_t match_dl[kMaxMatches];  // (dst - round_start) | len << 15
-    uint16_t match_dist[kMaxMatches];  // dist - 1
+    uint32_t win[kWinWords + 4];      // staged input; reused as u16 source pointers by the copy phase
+    uint32_t litlen[kLitlenEnough];   // litlen and offset tables are adjacent: the decode
+    uint32_t offset[kOffsetEnough];   // loops index both relative to litlen[0]
+    union {
+        HeaderScratch hdr;
+        SpecScratch spec;
+        MatchQueue mq;
+    };
     uint32_t lane_exit[kT];
     uint32_t scan_carry[2 * (kT / 64)];
     uint32_t emit_error;          // min over lanes of lane << 8 | DecompressResult
     uint32_t stat_spec, stat_copy; // pass counters (STATS builds)
     uint32_t first_flag;          // first lane whose sub-sequence ends the block / the input
-    uint16_t sorted_syms[288];
-    uint8_t lens[288 + 32 + 140];
-    uint8_t precode_lens[20];
-    uint32_t first_open[kT / 64];
-    uint32_t done_bits[kT / 32];  // finished matches of the current copy batch
-    // control block written by thread 0, read by all after a barrier
+    unsigned long long stat_t[4]; // development timers: first pass, later passes, prefix, emit
+    // control block written by one lane, read by all after a barrier
     uint32_t litlen_tablebits;
     uint32_t num_matches;
     uint32_t round_start_lo, round_end_lo;  // output positions (streams are < 4 GiB)
@@ -285,7 +309,7 @@ __device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *w
         }
         reinterpret_cast<uint4 *>(L.win)[u] = v;
     }
-    if (threadIdx.x < 2) L.win[kWinWords + threadIdx.x] = 0;
+    if (threadIdx.x < 4) L.win[kWinWords + threadIdx.x] = 0;
 }
 
 // Read the 14-bit dynamic header + code lengths (src/decompress/mod.rs:403-507)
@@ -305,31 +329,31 @@ __device__ __noinline__ int read_dynamic_header(StreamLds &L, uint32_t *bp, int6
     uint32_t i;
     for (i = 0; i < num_precode; i++) {
         if (!avail(3)) return RSX_SHORT_INPUT;
-        L.precode_lens[c_precode_perm[i]] = fetch_bits(L.win, b) & 7;
+        L.hdr.precode_lens[c_precode_perm[i]] = fetch_bits(L.win, b) & 7;
         b += 3;
     }
-    for (; i < 19; i++) L.precode_lens[c_precode_perm[i]] = 0;
-    if (!build_decode_table(L.precode, L.precode_lens, 19, KIND_PRECODE, kPrecodeBits, 7,
-                            L.sorted_syms, nullptr))
+    for (; i < 19; i++) L.hdr.precode_lens[c_precode_perm[i]] = 0;
+    if (!build_decode_table(L.hdr.precode, L.hdr.precode_lens, 19, KIND_PRECODE, kPrecodeBits, 7,
+                            L.hdr.sorted_syms, nullptr))
         return RSX_BAD_DATA;
     const uint32_t total = num_litlen + num_offset;
     i = 0;
     while (i < total) {
         bits = fetch_bits(L.win, b);
-        uint32_t e = L.precode[bits & ((1u << kPrecodeBits) - 1)];
+        uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
         uint32_t nbits = e & 0xFF;
         if (!avail(nbits)) return RSX_SHORT_INPUT;
         b += nbits;
         bits >>= nbits;
         uint32_t presym = e >> 16;
         if (presym < 16) {
-            L.lens[i++] = (uint8_t)presym;
+            L.hdr.lens[i++] = (uint8_t)presym;
             continue;
         }
         uint32_t rep, val, xb;
         if (presym == 16) {
             if (i == 0) return RSX_BAD_DATA;
-            val = L.lens[i - 1];
+            val = L.hdr.lens[i - 1];
             xb = 2;
             rep = 3;
         } else if (presym == 17) {
@@ -345,14 +369,14 @@ __device__ __noinline__ int read_dynamic_header(StreamLds &L, uint32_t *bp, int6
         rep += bits & ((1u << xb) - 1);
         b += xb;
         // a run passing the end is clamped (src/decompress/mod.rs:462-467)
-        while (rep-- && i < total) L.lens[i++] = (uint8_t)val;
+        while (rep-- && i < total) L.hdr.lens[i++] = (uint8_t)val;
     }
     *bp = b;
-    if (!build_decode_table(L.offset, L.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
-                            L.sorted_syms, nullptr))
+    if (!build_decode_table(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
+                            L.hdr.sorted_syms, nullptr))
         return RSX_BAD_DATA;
-    if (!build_decode_table(L.litlen, L.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
-                            L.sorted_syms, &L.litlen_tablebits))
+    if (!build_decode_table(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
+                            L.hdr.sorted_syms, &L.litlen_tablebits))
         return RSX_BAD_DATA;
     return RSX_SUCCESS;
 }
@@ -361,14 +385,14 @@ __device__ __noinline__ int read_dynamic_header(StreamLds &L, uint32_t *bp, int6
 __device__ __noinline__ void load_static_codes(StreamLds &L)
 {
     uint32_t i = 0;
-    for (; i < 144; i++) L.lens[i] = 8;
-    for (; i < 256; i++) L.lens[i] = 9;
-    for (; i < 280; i++) L.lens[i] = 7;
-    for (; i < 288; i++) L.lens[i] = 8;
-    for (; i < 320; i++) L.lens[i] = 5;
-    build_decode_table(L.offset, L.lens + 288, 32, KIND_OFFSET, kOffsetBits, 15, L.sorted_syms,
+    for (; i < 144; i++) L.hdr.lens[i] = 8;
+    for (; i < 256; i++) L.hdr.lens[i] = 9;
+    for (; i < 280; i++) L.hdr.lens[i] = 7;
+    for (; i < 288; i++) L.hdr.lens[i] = 8;
+    for (; i < 320; i++) L.hdr.lens[i] = 5;
+    build_decode_table(L.offset, L.hdr.lens + 288, 32, KIND_OFFSET, kOffsetBits, 15, L.hdr.sorted_syms,
                        nullptr);
-    build_decode_table(L.litlen, L.lens, 288, KIND_LITLEN, kLitlenBits, 15, L.sorted_syms,
+    build_decode_table(L.litlen, L.hdr.lens, 288, KIND_LITLEN, kLitlenBits, 15, L.hdr.sorted_syms,
                        &L.litlen_tablebits);
 }
 
@@ -427,90 +451,86 @@ __device__ __noinline__ void header_step(StreamLds &L, const StreamCtx &c, int64
     L.bitpos = (uint64_t)(win_bit0 + b);
 }
 
-// One decoded token.  kind: 0 literal, 1 match, 2 end of block.
-struct Token {
-    uint32_t nbits;  // bits consumed by the whole token
-    uint32_t kind;
-    uint32_t value;  // literal byte, or match length
-    uint32_t dist;
-};
-
-// Per-lane bit buffer over the staged window: at least 32 valid bits after
-// refill(), one LDS dword read per 32 consumed bits.
-struct BitReader {
+// ---- the symbol decoder ------------------------------------------------------------
+// Each lane runs a small state machine whose every step is ONE table lookup: a
+// litlen root entry, an offset root entry or a subtable entry.  A literal takes one
+// step, a match two (length, distance), long codes one more.  Lanes in different
+// states execute the same instructions (selects, no data-dependent branches), so a
+// wave that holds literals, match halves and subtable hops at once does not diverge.
+//
+// Bit buffer: 64 bits per lane, refilled 32 bits at a time from the staged window;
+// the next window dword is always already loaded, so a refill adds no LDS round
+// trip to the step-to-step dependency chain.
+struct Decoder {
     uint64_t bb;     // unread bits, LSB first
     uint32_t bc;     // valid bits in bb
-    uint32_t wnext;  // next window dword to load
+    uint32_t wnext;  // index of the prefetched window dword
+    uint32_t nextw;  // win[wnext]
+    uint32_t b;      // window bit position of the next unread bit
+    uint32_t tok;    // window bit position where the current token starts
+    uint32_t pend;   // match length waiting for its distance (0 = litlen phase)
+    uint32_t tbase;  // table index base of the next lookup (relative to litlen[0])
+    uint32_t tmask;  // index mask of the next lookup
 
-    __device__ inline void init(const StreamLds &L, uint32_t b)
+    __device__ inline void init(const StreamLds &L, uint32_t at, uint32_t litlen_mask)
     {
-        const uint32_t w = b >> 5;
-        bb = (((uint64_t)L.win[w + 1] << 32) | L.win[w]) >> (b & 31);
-        bc = 64 - (b & 31);
+        const uint32_t w = at >> 5;
+        bb = (((uint64_t)L.win[w + 1] << 32) | L.win[w]) >> (at & 31);
+        bc = 64 - (at & 31);
         wnext = w + 2;
-    }
-    __device__ inline void refill(const StreamLds &L)
-    {
-        if (bc < 32) {
-            bb |= (uint64_t)L.win[wnext++] << bc;
-            bc += 32;
-        }
-    }
-    __device__ inline void consume(uint32_t n)
-    {
-        bb >>= n;
-        bc -= n;
+        nextw = L.win[wnext];
+        b = tok = at;
+        pend = 0;
+        tbase = 0;
+        tmask = litlen_mask;
     }
 };
 
-// Decode the token at the reader's position.  Bits past the end of the body
-// read as zero; the caller checks nbits against the bits really available.
-__device__ inline Token decode_token(const StreamLds &L, BitReader &r, uint32_t litlen_mask)
+// result of one step
+struct StepOut {
+    uint32_t kind;   // 0 nothing finished (length read / subtable hop), 1 literal, 2 match, 3 end of block
+    uint32_t value;  // literal byte / match distance (the length is Decoder::pend before the step)
+    uint32_t len;    // match length when kind == 2
+};
+
+__device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d, uint32_t litlen_mask)
 {
-    Token t;
-    r.refill(L);
-    uint32_t bits = (uint32_t)r.bb;
-    uint32_t e = L.litlen[bits & litlen_mask];
-    uint32_t used = 0;
-    if ((e & (kExceptional | kSubtable)) == (kExceptional | kSubtable)) {
-        used = e & 0xFF;
-        bits >>= used;
-        e = L.litlen[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
-    }
-    uint32_t total_bits = e & 0xFF;
-    used += total_bits;
-    r.consume(used);
-    t.nbits = used;
-    t.dist = 0;
-    if (e & kLiteral) {
-        t.kind = 0;
-        t.value = (e >> 16) & 0xFF;
-        return t;
-    }
-    if (e & kEndOfBlock) {
-        t.kind = 2;
-        t.value = 0;
-        return t;
-    }
-    uint32_t clen = (e >> 8) & 0xFF;
-    t.kind = 1;
-    t.value = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
-    r.refill(L);
-    bits = (uint32_t)r.bb;
-    e = L.offset[bits & ((1u << kOffsetBits) - 1)];
-    used = 0;
-    if (e & kSubtable) {
-        used = e & 0xFF;
-        bits >>= used;
-        e = L.offset[(e >> 16) + (bits & ((1u << ((e >> 8) & 0x3F)) - 1))];
-    }
-    total_bits = e & 0xFF;
-    clen = (e >> 8) & 0xFF;
-    t.dist = (e >> 16) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
-    used += total_bits;
-    r.consume(used);
-    t.nbits += used;
-    return t;
+    // refill: bc >= 32 afterwards
+    const bool low = d.bc < 32;
+    d.bb |= low ? (uint64_t)d.nextw << d.bc : 0ull;
+    d.bc += low ? 32u : 0u;
+    d.wnext += low ? 1u : 0u;
+    if (low) d.nextw = L.win[d.wnext];
+
+    const uint32_t bits = (uint32_t)d.bb;
+    const uint32_t e = L.litlen[d.tbase + (bits & d.tmask)];
+    const bool in_off = d.pend != 0;
+    const bool is_ptr = (e & kSubtable) != 0;
+    const bool is_lit = (e & kLiteral) != 0;
+    const bool is_eob = !is_ptr && (e & kEndOfBlock) != 0;
+    const uint32_t total_bits = e & 0xFF, clen = (e >> 8) & 0xFF;
+    // a pointer consumes the root bits (its low byte); a final entry code + extra bits
+    const uint32_t value = ((e >> 16) & 0x7FFF) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
+    d.bb >>= total_bits;
+    d.bc -= total_bits;
+    d.b += total_bits;
+
+    StepOut o;
+    const bool fin_off = !is_ptr && in_off;
+    const bool fin_lit = !is_ptr && !in_off && is_lit;
+    const bool fin_len = !is_ptr && !in_off && !is_lit && !is_eob;
+    o.kind = fin_off ? 2u : fin_lit ? 1u : (is_eob && !in_off) ? 3u : 0u;
+    o.value = value;
+    o.len = d.pend;
+    // next state
+    const uint32_t base_now = in_off ? (uint32_t)kLitlenEnough : 0u;
+    const uint32_t npend = fin_len ? value : (is_ptr ? d.pend : 0u);
+    const bool next_off = npend != 0;
+    d.tbase = is_ptr ? base_now + ((e >> 16) & 0x3FFF) : (next_off ? (uint32_t)kLitlenEnough : 0u);
+    d.tmask = is_ptr ? (1u << ((e >> 8) & 0x3F)) - 1 : (next_off ? (1u << kOffsetBits) - 1 : litlen_mask);
+    d.pend = npend;
+    d.tok = (fin_off || fin_lit) ? d.b : d.tok;
+    return o;
 }
 
 // What one lane learns from decoding its sub-sequence without emitting.
@@ -520,32 +540,31 @@ struct Scan {
     uint32_t nm;     // matches among them
 };
 
-// Decode tokens that start in [start, bound); end_b = first bit past the body.
+// Decode tokens that start in [start, bound); end_b = first bit past the body
+// (window relative).  Bits past the body read as zero; a step that runs past the
+// body stops the chain at the start of its token (ShortInput when it is real).
 __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bound, int64_t end_b,
                                  uint32_t litlen_mask)
 {
     Scan r{start, 0, 0};
-    uint32_t b = start;
-    BitReader br;
-    br.init(L, b);
-    while (b < bound) {
-        Token t = decode_token(L, br, litlen_mask);
-        if ((int64_t)(b + t.nbits) > end_b) {
-            r.exit = b | kExitStop;
+    Decoder d;
+    d.init(L, start, litlen_mask);
+    // a token is in flight while tok != b (length read, subtable hop)
+    while (d.tok != d.b || d.b < bound) {
+        const uint32_t t0 = d.tok;
+        const StepOut o = decoder_step(L, d, litlen_mask);
+        if ((int64_t)d.b > end_b) {
+            r.exit = t0 | kExitStop;
             return r;
         }
-        b += t.nbits;
-        if (t.kind == 0) {
-            r.bytes += 1;
-        } else if (t.kind == 1) {
-            r.bytes += t.value;
-            r.nm += 1;
-        } else {
-            r.exit = b | kExitEob;
+        r.bytes += o.kind == 2 ? o.len : (o.kind == 1 ? 1u : 0u);
+        r.nm += o.kind == 2 ? 1u : 0u;
+        if (o.kind == 3) {
+            r.exit = d.b | kExitEob;
             return r;
         }
     }
-    r.exit = b;
+    r.exit = d.b;
     return r;
 }
 
@@ -593,34 +612,75 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     uint32_t bound = lo + kSubBits;
     if (bound > kWinLimitBits) bound = kWinLimitBits;
 
-    // ---- passes 1..k: find every lane's true start ------------------------------
+    // ---- passes 1..k: find every sub-sequence's true start ------------------------
     // A lane that decodes an end-of-block (or runs out of input) while its start is
     // still a guess must not silence the lanes behind it: they keep their own guess
     // until the chain in front of them is settled.
+    // Pass 1 decodes every sub-sequence from its guess.  After each pass the owner of
+    // sub-sequence i compares its start with where sub-sequence i-1 ended; the ones
+    // that changed are compacted into a work list and re-decoded by the first lanes
+    // of the workgroup, so late passes (few stragglers) occupy one wave, not all.
     uint32_t start = lo;          // lane 0's guess is exact
-    Scan sc{0, 0, 0};
-    bool need = true;
-    // the true prefix grows by at least one lane per pass, so kT passes always suffice
+    unsigned long long tq = RSX_DEV_TIMERS ? clock64() : 0;
+    Scan sc;
+    if (start >= bound) {
+        sc = Scan{start, 0, 0};   // nothing starts here (window exhausted)
+    } else {
+        sc = scan_span(L, start, bound, end_b, litlen_mask);
+    }
+    L.lane_exit[tid] = sc.exit;
+    L.spec.sub_bytes[tid] = (uint16_t)sc.bytes;
+    L.spec.sub_nm[tid] = (uint16_t)sc.nm;
+    __syncthreads();
+    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tq; tq = t; }
+    // the true prefix grows by at least one sub-sequence per pass, so kT passes suffice
     for (int pass = 0; pass <= kT; pass++) {
-        if (need) {
-            if (start >= bound) {
-                sc = Scan{start, 0, 0};  // nothing starts here (window exhausted or overshoot)
-            } else {
-                sc = scan_span(L, start, bound, end_b, litlen_mask);
-            }
-            L.lane_exit[tid] = sc.exit;
-        }
         __syncthreads();
         uint32_t ns = lo;
         if (tid > 0) {
             uint32_t pe = L.lane_exit[tid - 1];
             if (!(pe & (kExitEob | kExitStop))) ns = pe;
         }
-        need = ns != start;
+        const bool need = ns != start;
         start = ns;
-        if (tid == 0) L.stat_spec++;
-        if (!__syncthreads_or(need)) break;
+        // compact the sub-sequences that need another decode
+        const unsigned long long bal = __ballot(need);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) L.scan_carry[w] = (uint32_t)__popcll(bal);
+        if (need) L.spec.sub_start[tid] = start;
+        if (RSX_DEV_TIMERS && tid == 0) L.stat_spec++;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int k = 0; k < kT / 64; k++) {
+            uint32_t cnt = L.scan_carry[k];
+            if (k < w) before += cnt;
+            total += cnt;
+        }
+        if (total == 0) break;
+        if (need) L.spec.work[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)tid;
+        __syncthreads();
+        if ((uint32_t)tid < total) {
+            const uint32_t i = L.spec.work[tid];
+            const uint32_t st_i = L.spec.sub_start[i];
+            uint32_t bound_i = b0 + (i + 1) * kSubBits;
+            if (bound_i > kWinLimitBits) bound_i = kWinLimitBits;
+            Scan r;
+            if (st_i >= bound_i) {
+                r = Scan{st_i, 0, 0};   // the previous token overshoots this sub-sequence
+            } else {
+                r = scan_span(L, st_i, bound_i, end_b, litlen_mask);
+            }
+            L.lane_exit[i] = r.exit;
+            L.spec.sub_bytes[i] = (uint16_t)r.bytes;
+            L.spec.sub_nm[i] = (uint16_t)r.nm;
+        }
     }
+    __syncthreads();
+    sc.exit = L.lane_exit[tid];
+    sc.bytes = L.spec.sub_bytes[tid];
+    sc.nm = L.spec.sub_nm[tid];
+    __syncthreads();
+    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tq; tq = t; }
     // every start now follows from lane 0's: the first lane that ended the block
     // (or the input) is real, and nothing behind it belongs to this block
     if (tid == 0) {
@@ -645,48 +705,49 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     __syncthreads();
     const bool last = commit && (tid == kT - 1 || !(L.lane_exit[tid + 1] & 0x10000000u));
 
+    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tq; tq = t; }
     // ---- emit -------------------------------------------------------------------------
     if (commit) {
         uint32_t b = start;
         uint64_t op = (uint64_t)round_start + ex_bytes;
         uint32_t mi = ex_nm;
         int err = -1;
-        BitReader br;
-        br.init(L, b);
-        while (b < bound) {
-            Token t = decode_token(L, br, litlen_mask);
-            if ((int64_t)(b + t.nbits) > end_b) {
+        Decoder d;
+        d.init(L, b, litlen_mask);
+        while (d.tok != d.b || d.b < bound) {
+            const StepOut o = decoder_step(L, d, litlen_mask);
+            if ((int64_t)d.b > end_b) {
                 err = RSX_SHORT_INPUT;
                 break;
             }
-            b += t.nbits;
-            if (t.kind == 0) {
+            if (o.kind == 1) {
                 if (op >= c.out_cap) {
                     err = RSX_INSUFFICIENT_SPACE;
                     break;
                 }
-                L.ring[((uint32_t)op + c.shift) & kRingMask] = (uint8_t)t.value;
+                L.ring[((uint32_t)op + c.shift) & kRingMask] = (uint8_t)o.value;
                 op++;
-            } else if (t.kind == 1) {
-                if (t.dist > op) {
+            } else if (o.kind == 2) {
+                if (o.value > op) {
                     err = RSX_BAD_DATA;
                     break;
                 }
-                if (op + t.value > c.out_cap) {
+                if (op + o.len > c.out_cap) {
                     err = RSX_INSUFFICIENT_SPACE;
                     break;
                 }
-                L.match_dl[mi] = (uint32_t)(op - round_start) | (t.value << 15);
-                L.match_dist[mi] = (uint16_t)(t.dist - 1);
+                L.mq.dl[mi] = (uint32_t)(op - round_start) | (o.len << 15);
+                L.mq.dist[mi] = (uint16_t)(o.value - 1);
                 mi++;
-                op += t.value;
-            } else {
+                op += o.len;
+            } else if (o.kind == 3) {
                 break;
             }
         }
         if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
     }
     __syncthreads();
+    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tq; tq = t; }
     if (last) {
         const uint32_t ee = L.emit_error;
         L.bitpos = (uint64_t)(win_bit0 + (int64_t)(sc.exit & kExitPosMask));
@@ -702,11 +763,13 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     __syncthreads();
 }
 
-// All lanes: resolve the queued matches of this round, kT at a time.  Inside a
-// batch a match waits only for the earlier matches whose destination overlaps its
-// source bytes (found by binary search in the queue, which is sorted by
-// destination); everything older is final.  Passes per batch = depth of the
-// dependency chain, not the number of near matches.
+// All lanes: resolve the queued matches of this round, kCopySub output bytes at a
+// time.  Every output byte of the step gets a 16-bit pointer to the byte it copies
+// (literals point to themselves); pointer jumping (ptr = ptr[ptr]) then makes every
+// pointer refer to a byte that is already final -- a literal of this step or data in
+// front of it -- in log2(chain length) rounds, whatever the dependency depth
+// between matches, overlapping (run-length) matches included.  One gather finishes
+// the step.  The pointers live in the window buffer, which is idle during the copy.
 __device__ void copy_round(StreamLds &L, const StreamCtx &c)
 {
     const uint32_t nm = L.num_matches;
@@ -715,99 +778,67 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     // positions >= lds_lo are still in the ring once the round is complete
     const int64_t lds_lo = (int64_t)round_end - (int64_t)kRing;
     const int tid = threadIdx.x;
-    for (uint32_t base = 0; base < nm; base += kT) {
-        const uint32_t m = base + tid;
-        const bool have = m < nm;
-        uint32_t dst = 0, len = 0, dist = 1;
-        uint32_t dep_a = 0, dep_b = 0;  // batch-relative range of matches my source overlaps
-        if (tid < kT / 32) L.done_bits[tid] = 0;
-        if (have) {
-            uint32_t q = L.match_dl[m];
-            const uint32_t drel = q & 0x7FFF;
-            dst = round_start + drel;
-            len = q >> 15;
-            dist = (uint32_t)L.match_dist[m] + 1;
-            // source bytes [s, s_end) relative to round_start (s may lie before the round)
-            const int32_t s = (int32_t)drel - (int32_t)dist;
-            const int32_t s_end = s + (int32_t)(len < dist ? len : dist);
-            if (s_end > 0) {
-                // first match in [base, m) whose end is behind s
-                uint32_t lo = base, hi = m;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    uint32_t qq = L.match_dl[mid];
-                    if ((int32_t)((qq & 0x7FFF) + (qq >> 15)) > s) hi = mid; else lo = mid + 1;
-                }
-                dep_a = lo - base;
-                uint32_t j = lo;
-                while (j < m && (int32_t)(L.match_dl[j] & 0x7FFF) < s_end) j++;
-                dep_b = j - base;
-            }
-        }
-        bool done = !have, published = !have;
+    uint16_t *ptr = reinterpret_cast<uint16_t *>(L.win);
+    constexpr uint32_t kSelf = 0xFFFF;
+    constexpr uint32_t kBack = 32768;   // pointer value v refers to position sub_start - kBack + v
+    uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
+    __syncthreads();
+    for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub) {
+        const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
+        const uint32_t n = sub_end - sub_start;
+        for (uint32_t i = tid; i < n; i += kT) ptr[i] = (uint16_t)kSelf;
         __syncthreads();
-        // the first unfinished match of a batch can always run, so kT passes suffice
-        for (int pass = 0; pass <= kT; pass++) {
-            if (!done) {
-                bool ready = true;
-                for (uint32_t j = dep_a; j < dep_b; j++)
-                    if (!((L.done_bits[j >> 5] >> (j & 31)) & 1)) {
-                        ready = false;
-                        break;
+        // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
+        uint32_t consumed = 0;
+        for (uint32_t m = mcur + tid; m < nm; m += kT) {
+            const uint32_t q = L.mq.dl[m];
+            const uint32_t dst = round_start + (q & 0x7FFF), len = q >> 15;
+            if (dst >= sub_end) break;
+            const uint32_t dist = (uint32_t)L.mq.dist[m] + 1;
+            const uint32_t from = dst > sub_start ? dst : sub_start;
+            const uint32_t to = dst + len < sub_end ? dst + len : sub_end;
+            // source position p - dist, encoded relative to sub_start - kBack
+            const uint32_t bias = kBack - dist - sub_start;
+            for (uint32_t pos = from; pos < to; pos++) ptr[pos - sub_start] = (uint16_t)(pos + bias);
+            if (dst + len <= sub_end) consumed++;
+        }
+        // advance mcur by the number of matches that end inside this step
+        {
+            uint32_t x = consumed;
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if ((tid & 63) == 0) L.scan_carry[tid >> 6] = x;
+        }
+        __syncthreads();
+        for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
+        // pointer jumping: a pointer into this step that lands on a non-literal byte
+        // takes over that byte's pointer
+        for (int round = 0; round < 16; round++) {
+            bool changed = false;
+            for (uint32_t i = tid; i < n; i += kT) {
+                const uint32_t v = ptr[i];
+                if (v != kSelf && v >= kBack) {
+                    const uint32_t v2 = ptr[v - kBack];
+                    if (v2 != kSelf) {
+                        ptr[i] = (uint16_t)v2;
+                        changed = true;
                     }
-                if (ready) {
-                    const uint32_t d0 = dst + c.shift, s0 = d0 - dist;
-                    if ((int64_t)dst - dist < lds_lo) {
-                        // far source: part of it has left the ring, read that from the output
-                        for (uint32_t k = 0; k < len; k++) {
-                            int64_t sp = (int64_t)dst + k - dist;
-                            uint8_t v = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask]
-                                                     : c.out[sp];
-                            L.ring[(d0 + k) & kRingMask] = v;
-                        }
-                    } else if (dist >= 8) {
-                        // 8 independent loads, then 8 stores: one LDS round trip per 8 bytes
-                        uint32_t k = 0;
-                        for (; k + 8 <= len; k += 8) {
-                            uint8_t v[8];
-#pragma unroll
-                            for (int j = 0; j < 8; j++) v[j] = L.ring[(s0 + k + j) & kRingMask];
-#pragma unroll
-                            for (int j = 0; j < 8; j++) L.ring[(d0 + k + j) & kRingMask] = v[j];
-                        }
-                        uint8_t v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (k + j < len) v[j] = L.ring[(s0 + k + j) & kRingMask];
-#pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (k + j < len) L.ring[(d0 + k + j) & kRingMask] = v[j];
-                    } else {
-                        // overlapping copy: the output repeats the last `dist` bytes
-                        uint64_t pat = 0;
-#pragma unroll
-                        for (uint32_t j = 0; j < 7; j++)
-                            if (j < dist) pat |= (uint64_t)L.ring[(s0 + j) & kRingMask] << (8 * j);
-                        uint32_t idx = 0;
-                        for (uint32_t k = 0; k < len; k++) {
-                            L.ring[(d0 + k) & kRingMask] = (uint8_t)(pat >> (8 * idx));
-                            idx = idx + 1 == dist ? 0 : idx + 1;
-                        }
-                    }
-                    done = true;
-                    dep_a = dep_b = 0;
                 }
             }
-            if (tid == 0) L.stat_copy++;
-            __syncthreads();  // copies of this pass are visible before their done bits
-            if (done && !published) {
-                atomicOr(&L.done_bits[tid >> 5], 1u << (tid & 31));
-                published = true;
+            if (!__syncthreads_or(changed)) break;
+        }
+        // gather: sources are literals of this step, earlier bytes of the round (ring) or
+        // bytes that have left the ring (read back from the output)
+        for (uint32_t i = tid; i < n; i += kT) {
+            const uint32_t v = ptr[i];
+            if (v != kSelf) {
+                const int64_t sp = (int64_t)sub_start - kBack + v;
+                const uint8_t byte = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask] : c.out[sp];
+                L.ring[(sub_start + i + c.shift) & kRingMask] = byte;
             }
-            if (!__syncthreads_or(!done)) break;
         }
         __syncthreads();
     }
+    __syncthreads();
 }
 
 // All lanes: write output positions [from, to) from the ring to global memory.
@@ -891,7 +922,7 @@ __device__ ContainerInfo parse_container(int format, const uint8_t *in, uint64_t
 // stats[item*8 + k]: 0 rounds, 1 speculation passes, 2 copy passes, 3..7 cycles in
 // stage / header / decode / copy / flush
 template <bool STATS>
-__global__ __launch_bounds__(kT) void inflate_kernel(
+__global__ __launch_bounds__(kT, 4) void inflate_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
@@ -937,6 +968,7 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
         L.emit_error = ~0u;
         L.stat_spec = 0;
         L.stat_copy = 0;
+        L.stat_t[0] = L.stat_t[1] = L.stat_t[2] = L.stat_t[3] = 0;
         L.round_start_lo = 0;
         L.round_end_lo = 0;
         L.num_matches = 0;
@@ -1065,9 +1097,10 @@ __global__ __launch_bounds__(kT) void inflate_kernel(
         // first byte behind the DEFLATE stream, relative to the item start
         body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
         if (STATS) {
-            unsigned long long *q = stats + (size_t)item * 8;
+            unsigned long long *q = stats + (size_t)item * 12;
             q[0] = nRounds; q[1] = L.stat_spec; q[2] = L.stat_copy;
-            q[3] = tS; q[4] = tH; q[5] = tD; q[6] = tC; q[7] = tF;
+            q[3] = L.stat_t[0]; q[4] = tH; q[5] = tD; q[6] = tC; q[7] = L.stat_t[1];
+            q[8] = L.stat_t[2]; q[9] = L.stat_t[3]; q[10] = tS; q[11] = tF;
         }
     }
 #undef STAT_BEGIN
@@ -1126,7 +1159,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     const bool want_stats = getenv("RSX_INFLATE_STATS") != nullptr;
     unsigned long long *d_stats = nullptr;
     if (want_stats) {
-        RSX_HIP(e, hipMalloc(&d_stats, n * 8 * sizeof(unsigned long long)));
+        RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
     }
     (void)hipEventRecord(e->ev_begin, e->stream);
     if (want_stats)
@@ -1137,18 +1170,20 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
             format, in, in_off, (uint32_t)n, total_in, out, out_off, out_sizes, status, body_end, nullptr);
     (void)hipEventRecord(e->ev_end, e->stream);
     if (want_stats) {
-        std::vector<unsigned long long> h(n * 8);
+        std::vector<unsigned long long> h(n * 12);
         RSX_HIP(e, hipMemcpy(h.data(), d_stats, h.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(d_stats);
-        unsigned long long sum[8] = {0};
+        unsigned long long sum[12] = {0};
         for (size_t i = 0; i < n; i++)
-            for (int k = 0; k < 8; k++) sum[k] += h[i * 8 + k];
+            for (int k = 0; k < 12; k++) sum[k] += h[i * 12 + k];
         fprintf(stderr,
                 "[rsx inflate stats] streams %zu rounds %.1f spec_passes/round %.2f copy_passes/round %.2f "
-                "cycles/stream: stage %.0f header %.0f decode %.0f copy %.0f flush %.0f\n",
+                "cycles/stream: stage %.0f header %.0f decode %.0f (pass1 %.0f later %.0f prefix %.0f emit %.0f) "
+                "copy %.0f flush %.0f\n",
                 n, (double)sum[0] / n, (double)sum[1] / (double)sum[0], (double)sum[2] / (double)sum[0],
-                (double)sum[3] / n, (double)sum[4] / n, (double)sum[5] / n, (double)sum[6] / n,
-                (double)sum[7] / n);
+                (double)sum[10] / n, (double)sum[4] / n, (double)sum[5] / n, (double)sum[3] / n,
+                (double)sum[7] / n, (double)sum[8] / n, (double)sum[9] / n, (double)sum[6] / n,
+                (double)sum[11] / n);
     }
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
