@@ -41,13 +41,18 @@ namespace {
 
 constexpr int kCT = 512;                        // threads per chunk
 constexpr uint32_t kChunk = 256 * 1024;         // src/compress/mod.rs:699-700
-constexpr int kHashBits = 14;                   // 32-bit LDS exchange words: 2^14 heads = 64 KiB
+constexpr int kHashBits = 13;                   // 32-bit LDS exchange words: 2^13 heads = 32 KiB
                                                 // (the reference hashes to 15 bits, matchfinder.rs:784)
+constexpr int kHash3Bits = 11;
+constexpr uint32_t kMaxDist3 = 4096;           // farthest match of length 3 worth its offset bits
 constexpr uint32_t kWindow = 32768;
 constexpr uint32_t kBlockSoft = 65535 - 512 - 300;  // close the block once it holds this many bytes
 constexpr uint32_t kTokCap = 66 * 1024;         // tokens per block (<= bytes per block)
 constexpr uint32_t kScratchPad = 256;           // chunk scratch = chunk_len + kScratchPad
-constexpr uint16_t kNone = 0xFFFF;
+// LDS copy of the input around the current batch: 32 KiB of history, the batch, and
+// the longest match behind it; slid forward kInSlide bytes at a time
+constexpr uint32_t kInSlide = 4096;
+constexpr uint32_t kInBuf = kWindow + kInSlide + 2048;
 
 __constant__ uint16_t k_len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,
                                         15, 17, 19, 23, 27, 31, 35, 43, 51,  59,
@@ -93,8 +98,10 @@ __device__ inline uint32_t offset_slot(uint32_t dist)
 }
 
 struct __align__(16) ChunkLds {
-    uint32_t head[1 << kHashBits];   // newest position (mod 65536) per hash, kNone = empty
-    uint16_t prev[kWindow];          // older position (mod 65536) with the same hash
+    uint8_t inbuf[kInBuf + 32];      // input bytes [w0 - phase, w0 - phase + kInBuf) of the chunk
+    uint32_t head[1 << kHashBits];   // newest position + 1 per 4-byte hash, 0 = empty
+    uint32_t head3[1 << kHash3Bits]; // newest position + 1 per 3-byte hash
+    uint16_t prev[kWindow];          // distance to the next older position with the same hash
     uint16_t m_len[kCT + 2];         // best match per parse slot: slot 0 = last position of the
     uint16_t m_off[kCT + 2];         //   previous batch, slots 1..kCT = this batch
     uint16_t jump[2][kCT + 2];       // pointer-jumping tables (slot -> slot, kCT+1 = past the end)
@@ -113,6 +120,7 @@ struct __align__(16) ChunkLds {
     uint32_t body_bits_lo;
     uint32_t block_mode;      // 2 dynamic, 0 stored
     uint32_t huff_scratch[288 + 32];
+    uint32_t len_counts[2][16];
 };
 
 // ---- bit output: the chunk scratch is zeroed up front, every write is an OR ----
@@ -136,14 +144,14 @@ constexpr uint32_t kFreqMask = ~kSymMask;
 
 __device__ inline uint32_t reverse_bits(uint32_t c, uint32_t len) { return __brev(c) >> (32 - len); }
 
-// lens[] / codes[] for num_syms symbols; a = scratch of num_syms words.
+// lens[] / codes[] for num_syms <= 32 symbols; a = scratch of num_syms words.
 __device__ __noinline__ void make_huffman_code(uint32_t num_syms, uint32_t max_len,
                                                const uint32_t *freqs, uint8_t *lens, uint32_t *codes,
                                                uint32_t *a)
 {
     // sort_symbols (huffman_comp.rs:8-36): counting sort on min(freq, num_syms-1), then the
     // last bucket by full key
-    uint32_t counters[288];
+    uint32_t counters[32];
     for (uint32_t i = 0; i < num_syms; i++) counters[i] = 0;
     for (uint32_t s = 0; s < num_syms; s++) {
         uint32_t f = freqs[s] < num_syms - 1 ? freqs[s] : num_syms - 1;
@@ -244,14 +252,128 @@ __device__ __noinline__ void make_huffman_code(uint32_t num_syms, uint32_t max_l
     }
 }
 
-// One lane: Huffman codes for the open block, block type decision and the block
+
+// ---- the same construction spread over the workgroup --------------------------------
+// Sorting, length assignment and codeword numbering are data parallel; only the
+// two-queue tree build and the length-limiting walk (huffman_comp.rs:38-89) stay on one
+// lane, and the literal/length and offset alphabets run them on two different waves.
+
+// one lane: a[0..used) sorted (freq << 10 | sym) -> len_counts[1..max_len]; a[] keeps the
+// symbols in its low bits
+__device__ __noinline__ void huff_tree_serial(uint32_t *a, uint32_t used, uint32_t max_len,
+                                              uint32_t *len_counts)
+{
+    {
+        uint32_t last = used - 1, i = 0, b = 0, e = 0;
+        while (e < last) {
+            uint32_t nf;
+            if (i < last && (b == e || (a[i + 1] & kFreqMask) <= (a[b] & kFreqMask))) {
+                nf = (a[i] & kFreqMask) + (a[i + 1] & kFreqMask);
+                i += 2;
+            } else if (b + 2 <= e && (i > last || (a[b + 1] & kFreqMask) < (a[i] & kFreqMask))) {
+                nf = (a[b] & kFreqMask) + (a[b + 1] & kFreqMask);
+                a[b] = (e << kSymBits) | (a[b] & kSymMask);
+                a[b + 1] = (e << kSymBits) | (a[b + 1] & kSymMask);
+                b += 2;
+            } else {
+                nf = (a[i] & kFreqMask) + (a[b] & kFreqMask);
+                a[b] = (e << kSymBits) | (a[b] & kSymMask);
+                i += 1;
+                b += 1;
+            }
+            a[e] = nf | (a[e] & kSymMask);
+            e++;
+        }
+    }
+    for (uint32_t l = 0; l < 16; l++) len_counts[l] = 0;
+    len_counts[1] = 2;
+    const uint32_t root = used - 2;
+    a[root] &= kSymMask;
+    for (int node = (int)root - 1; node >= 0; node--) {
+        uint32_t parent = a[node] >> kSymBits;
+        uint32_t depth = (a[parent] >> kSymBits) + 1;
+        a[node] = (a[node] & kSymMask) | (depth << kSymBits);
+        if (depth >= max_len) {
+            depth = max_len - 1;
+            while (len_counts[depth] == 0) depth--;
+        }
+        len_counts[depth]--;
+        len_counts[depth + 1] += 2;
+    }
+}
+
+// All lanes: codes of the literal/length alphabet (lanes 0..287 hold its symbols) and the
+// offset alphabet (lanes 320..351) of the open block.
+__device__ void build_block_codes(ChunkLds &L)
+{
+    const uint32_t tid = threadIdx.x;
+    const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
+    const uint32_t sym = is_ll ? tid : tid - 320;
+    const uint32_t num_syms = is_ll ? 288u : 32u;
+    const uint32_t max_len = is_ll ? 14u : 15u;
+    const uint32_t *freq = is_ll ? L.litlen_freq : L.off_freq;
+    uint8_t *lens = is_ll ? L.litlen_len : L.off_len;
+    uint32_t *codes = is_ll ? L.litlen_code : L.off_code;
+    uint32_t *a = is_ll ? L.huff_scratch : L.huff_scratch + 288;
+    uint32_t *len_counts = is_ll ? L.len_counts[0] : L.len_counts[1];
+    const bool on = is_ll || is_off;
+
+    // rank sort on (freq, sym) == the order of huffman_comp.rs:8-36
+    uint32_t used = 0;
+    if (on) {
+        const uint32_t f = freq[sym], key = (f << kSymBits) | sym;
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < num_syms; t++) {
+            const uint32_t ft = freq[t], kt = (ft << kSymBits) | t;
+            used += ft != 0;
+            rank += (ft != 0) & (kt < key);
+        }
+        codes[sym] = 0;
+        lens[sym] = 0;
+        if (f) a[rank] = key;
+    }
+    __syncthreads();
+    if (on && sym == 0) {
+        if (used < 2) {
+            // huffman_comp.rs:133-145: two 1-bit codes so the code is complete
+            uint32_t s0 = used ? (a[0] & kSymMask) : 0;
+            uint32_t nz = s0 ? s0 : 1;
+            codes[0] = 0;
+            lens[0] = 1;
+            codes[nz] = 1;
+            lens[nz] = 1;
+        } else {
+            huff_tree_serial(a, used, max_len, len_counts);
+        }
+    }
+    __syncthreads();
+    // gen_codewords (huffman_comp.rs:95-123): sorted index i takes the longest lengths first
+    if (on && used >= 2 && sym < used) {
+        uint32_t c = 0, len = max_len;
+        for (; len >= 1; len--) {
+            c += len_counts[len];
+            if (sym < c) break;
+        }
+        lens[a[sym] & kSymMask] = (uint8_t)len;
+    }
+    __syncthreads();
+    if (on && used >= 2) {
+        const uint32_t len = lens[sym];
+        if (len) {
+            uint32_t next = 0;
+            for (uint32_t l = 2; l <= len; l++) next = (next + len_counts[l - 1]) << 1;
+            for (uint32_t t = 0; t < sym; t++) next += lens[t] == len;
+            codes[sym] = reverse_bits(next, len);
+        }
+    }
+    __syncthreads();
+}
+
+// One lane: block type decision and the block
 // header (src/compress/mod.rs:1375-1398, :1775-1883).  Returns through L.block_mode.
 __device__ __noinline__ void begin_block(ChunkLds &L, uint32_t *out_words, uint32_t block_bytes,
                                          bool is_final)
 {
-    L.litlen_freq[256] = 1;  // end of block
-    make_huffman_code(288, 14, L.litlen_freq, L.litlen_len, L.litlen_code, L.huff_scratch);
-    make_huffman_code(32, 15, L.off_freq, L.off_len, L.off_code, L.huff_scratch);
 
     // code-length sequence and its run-length items (mod.rs:1790-1839)
     uint32_t nl = 288, no = 32;
@@ -364,6 +486,13 @@ __device__ inline uint32_t token_bits(const ChunkLds &L, uint32_t t)
     return L.litlen_len[257 + ls] + k_len_extra[ls] + L.off_len[os] + k_off_extra[os];
 }
 
+#ifndef RSX_DEV_TIMERS
+#define RSX_DEV_TIMERS 0
+#endif
+// development timers (cycles summed over workgroups): slide, insert, search, parse, emit, flush
+__device__ unsigned long long g_deflate_t[12];
+#define DT_MARK(k) do { if (RSX_DEV_TIMERS && threadIdx.x == 0) { unsigned long long t_ = clock64(); dt[k] += t_ - tq; tq = t_; } } while (0)
+
 // exclusive prefix sum over the workgroup (returns the total through *total)
 __device__ inline uint32_t wg_exclusive_scan(ChunkLds &L, uint32_t v, uint32_t *total)
 {
@@ -395,9 +524,14 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
     const uint32_t ntok = L.block_ntok;
     const uint32_t bstart = L.block_start;
     const uint32_t block_bytes = block_end - bstart;
+    if (tid == 0) L.litlen_freq[256] = 1;  // end of block
     __syncthreads();
+    unsigned long long fq = RSX_DEV_TIMERS ? clock64() : 0;
+    build_block_codes(L);
+    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[6], t_ - fq); fq = t_; }
     if (tid == 0) begin_block(L, out_words, block_bytes, is_final);
     __syncthreads();
+    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[7], t_ - fq); fq = t_; }
     const uint64_t body0 = L.out_bits;
     if (L.block_mode == 0) {
         // stored: raw bytes behind LEN/NLEN (byte aligned)
@@ -477,6 +611,20 @@ __device__ inline uint32_t match_length(const uint8_t *a, const uint8_t *b, uint
     return n;
 }
 
+// Copy chunk positions [from, to) into the LDS input buffer with 16-byte units
+// aligned to the global address.  LDS index of chunk position p is p - w0 + phase.
+__device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, uint32_t w0,
+                                   uint32_t phase, uint32_t from, uint32_t to)
+{
+    if (to > n) to = n;
+    if (from >= to) return;
+    // unit u covers LDS bytes [16u, 16u+16) = global bytes in - phase + w0 + 16u ...
+    const uint32_t u0 = (from - w0 + phase) >> 4, u1 = (to - w0 + phase + 15) >> 4;
+    const uint8_t *g = in + w0 - phase;   // 16-byte aligned
+    for (uint32_t u = u0 + threadIdx.x; u < u1; u += kCT)
+        reinterpret_cast<uint4 *>(L.inbuf)[u] = *reinterpret_cast<const uint4 *>(g + 16 * (size_t)u);
+}
+
 // Compress one chunk (<= 256 KiB) into `out_words` (zeroed, chunk_len + kScratchPad
 // bytes).  Returns the number of bytes written (uniform over the workgroup).
 __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, bool last_chunk,
@@ -488,7 +636,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         uint4 *z = reinterpret_cast<uint4 *>(out_words);
         const uint32_t units = (n + kScratchPad) / 16;
         for (uint32_t u = tid; u < units; u += kCT) z[u] = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = tid; i < (1u << kHashBits); i += kCT) L.head[i] = kNone;
+        for (uint32_t i = tid; i < (1u << kHashBits); i += kCT) L.head[i] = 0;
+        for (uint32_t i = tid; i < (1u << kHash3Bits); i += kCT) L.head3[i] = 0;
         for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
         if (tid < 32) L.off_freq[tid] = 0;
         for (int i = tid; i < 260; i += kCT) {
@@ -505,6 +654,12 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.m_off[0] = 0;
         }
     }
+    __syncthreads();
+
+    // LDS input window
+    const uint32_t phase = (uint32_t)((uintptr_t)in & 15);
+    uint32_t w0 = 0, staged = kInBuf - 16 < n ? kInBuf - 16 : n;
+    if (lp.max_depth != 0) stage_input(L, in, n, 0, phase, 0, staged);
     __syncthreads();
 
     if (n == 0) {
@@ -538,61 +693,117 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         n = 0;  // nothing left for the matcher
     }
 
+    unsigned long long dt[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tq = RSX_DEV_TIMERS ? clock64() : 0;
     for (uint32_t b0 = 0; b0 < n; b0 += kCT) {
+        // ---- slide the LDS input window when the batch (plus the longest match) would
+        //      run off its end; 32 KiB of history stay behind b0 ---------------------------
+        if (b0 + kCT + 258 + 8 > w0 + kInBuf - 16 && staged < n) {
+            constexpr uint32_t kUnits = (kInBuf - kInSlide) / 16, kPer = (kUnits + kCT - 1) / kCT;
+            uint4 v[kPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; k++) {
+                uint32_t u = tid + k * kCT;
+                if (u < kUnits) v[k] = reinterpret_cast<const uint4 *>(L.inbuf)[u + kInSlide / 16];
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; k++) {
+                uint32_t u = tid + k * kCT;
+                if (u < kUnits) reinterpret_cast<uint4 *>(L.inbuf)[u] = v[k];
+            }
+            w0 += kInSlide;
+            __syncthreads();
+            const uint32_t upto = w0 + kInBuf - 16 < n ? w0 + kInBuf - 16 : n;
+            // restage from the 16-byte unit that holds `staged` (its head is already there)
+            stage_input(L, in, n, w0, phase, staged, upto);
+            staged = upto;
+            __syncthreads();
+        }
+        DT_MARK(0);
+        // LDS address of the input byte at chunk position q (q >= w0)
+        auto inp = [&](uint32_t q) -> const uint8_t * { return &L.inbuf[q + phase - w0]; };
         // ---- match: slot i+1 of the parse tables = position b0 + i ----------------
         const uint32_t p = b0 + tid;
         uint32_t best_len = 0, best_off = 0;
         const bool can = p + 3 <= n;   // matchfinder.rs:765-767
-        uint32_t h = 0, src3 = 0;
+        // chains link positions by a hash of 4 bytes; a second table remembers the newest
+        // position per 3-byte hash for the matches of length 3 the chains cannot see
+        const bool can4 = p + 4 <= n;
+        uint32_t h = 0, h3 = 0, src4 = 0;
         if (can) {
-            src3 = in[p] | (in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
-            h = (src3 * 0x1E35A7BDu) >> (32 - kHashBits);   // matchfinder.rs:784
+            src4 = load_le32(inp(p));   // bytes past the chunk end are never compared
+            h = (src4 * 0x1E35A7BDu) >> (32 - kHashBits);   // multiplier of matchfinder.rs:784
+            h3 = ((src4 << 8) * 0x1E35A7BDu) >> (32 - kHash3Bits);
         }
         // push on the chains one wave after the other, so that within a chain newer
-        // positions always sit in front of older ones (matchfinder.rs:788-805)
-        uint32_t older = kNone;
+        // positions always sit in front of older ones (matchfinder.rs:788-805).  Heads hold
+        // position + 1, links the distance to the next older position (0 ends the chain).
+        uint32_t link = 0, older3 = 0;
         for (int w = 0; w < kCT / 64; w++) {
             if ((tid >> 6) == w && can) {
-                older = atomicExch(&L.head[h], p & 0xFFFF);
-                L.prev[p & (kWindow - 1)] = (uint16_t)older;
+                if (can4) {
+                    const uint32_t o = atomicExch(&L.head[h], p + 1), dlt = p + 1 - o;
+                    link = (o != 0 && dlt < 65536) ? dlt : 0;
+                }
+                L.prev[p & (kWindow - 1)] = (uint16_t)link;
+                older3 = atomicExch(&L.head3[h3], p + 1);
             }
             __syncthreads();
         }
+        DT_MARK(1);
+        uint32_t stat_depth = 0;
         if (can && lp.max_depth) {
+            // Walk the chain (matchfinder.rs:808-870).  Per candidate one round of LDS
+            // reads (the link and 20 bytes of the candidate) decides lengths up to 20
+            // against the position's own first 20 bytes held in registers; only longer
+            // matches go through the extension loop.
             const uint32_t max_len = n - p < 258 ? n - p : 258;
-            const bool safe4 = p + 4 <= n;
-            const uint32_t src4 = safe4 ? load_le32(in + p) : src3;
-            uint32_t cur = p, stored = older, depth = 0;
-            while (stored != kNone && depth < lp.max_depth) {
-                uint32_t d = (cur - stored) & 0xFFFF;
-                if (d == 0 || d > cur) break;          // not an older position of this chunk
-                uint32_t cand = cur - d;
-                if (p - cand > 32768) break;           // matchfinder.rs:818
-                if (best_len >= max_len) break;        // matchfinder.rs:825
-                const uint8_t *m = in + cand;
-                bool ok = !(best_len >= 3 && m[best_len] != in[p + best_len]);
-                if (ok) {
-                    uint32_t m4 = load_le32(m);   // cand + 4 <= p + 3 <= n
-                    if (safe4 ? m4 == src4 : (m4 & 0xFFFFFF) == src3) {
-                        uint32_t l = match_length(m, in + p, max_len);
-                        if (l > best_len) {
-                            best_len = l;
-                            best_off = p - cand;
-                            if (l >= lp.nice_len || l == 258) break;
-                        }
-                    } else if (best_len < 3 && (m4 & 0xFFFFFF) == src3) {
-                        best_len = 3;
-                        best_off = p - cand;
-                    }
+            const uint32_t stop_len = lp.nice_len < max_len ? lp.nice_len : max_len;
+            const uint32_t max_dist = p < 32768 ? p : 32768;   // matchfinder.rs:818
+            const uint8_t *src = inp(p);
+            const uint64_t src_a = load_le64(src + 4), src_b = load_le64(src + 12);
+            uint32_t dist = 0;
+            bool alive = true;
+            for (uint32_t depth = 0; depth < lp.max_depth; depth++) {
+                dist += link;
+                if (!alive || link == 0 || dist > max_dist) break;
+                if (RSX_DEV_TIMERS) stat_depth++;
+                const uint32_t cand = p - dist;
+                const uint8_t *m = inp(cand);
+                link = L.prev[cand & (kWindow - 1)];
+                const uint32_t x4 = load_le32(m) ^ src4;
+                const uint64_t xa = load_le64(m + 4) ^ src_a, xb = load_le64(m + 12) ^ src_b;
+                const uint32_t la = xa ? 4 + ((uint32_t)(__ffsll((long long)xa) - 1) >> 3) : 12;
+                const uint32_t lb = xb ? 12 + ((uint32_t)(__ffsll((long long)xb) - 1) >> 3) : 20;
+                uint32_t l = x4 ? ((x4 & 0xFFFFFF) ? 0u : 3u) : (xa ? la : lb);
+                if (l == 20 && max_len > 20) l = 20 + match_length(m + 20, src + 20, max_len - 20);
+                l = l < max_len ? l : max_len;         // bytes past the chunk end do not count
+                const bool better = l > best_len;
+                best_len = better ? l : best_len;
+                best_off = better ? dist : best_off;
+                alive = l < stop_len;                  // matchfinder.rs:825, :851
+            }
+            if (best_len < 3 && older3 != 0) {
+                // length 3 only pays at short distances
+                const uint32_t d = p + 1 - older3;
+                if (d - 1 < kMaxDist3 && d <= p && ((load_le32(inp(p - d)) ^ src4) & 0xFFFFFF) == 0) {
+                    best_len = 3;
+                    best_off = d;
                 }
-                stored = L.prev[cand & (kWindow - 1)];
-                cur = cand;
-                depth++;
             }
         }
+#if RSX_DEV_TIMERS
+        {
+            uint32_t dsteps = stat_depth, m = dsteps, sum = dsteps;
+            for (int o = 32; o; o >>= 1) { uint32_t y = __shfl_xor(m, o); m = y > m ? y : m; sum += __shfl_xor(sum, o); }
+            if ((tid & 63) == 0) { atomicAdd(&g_deflate_t[8], (unsigned long long)sum); atomicAdd(&g_deflate_t[9], (unsigned long long)m * 64); }
+        }
+#endif
         L.m_len[tid + 1] = (uint16_t)best_len;
         L.m_off[tid + 1] = (uint16_t)(best_off - (best_off ? 1 : 0));  // dist-1 fits 15 bits
         __syncthreads();
+        DT_MARK(2);
 
         // ---- parse: slots [0, lim) are decided in this batch ----------------------
         // slot s <-> position b0 - 1 + s.  The last position of the batch waits for its
@@ -613,7 +824,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                     uint32_t len1 = (s + 1 < nslots) ? L.m_len[s + 1] : 0;
                     if (lp.lazy && len < lp.nice_len && len1 > len) {
                         // compress/mod.rs:1290-1336 (one lazy step): literal, then the longer match
-                        t0 = in[pos];
+                        t0 = *inp(pos);
                         t1 = tok_match(len1, (uint32_t)L.m_off[s + 1] + 1);
                         ntoks = 2;
                         my_next = s + 1 + len1;
@@ -623,7 +834,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                         my_next = s + len;
                     }
                 } else {
-                    t0 = in[pos];
+                    t0 = *inp(pos);
                     ntoks = 1;
                     my_next = s + 1;
                 }
@@ -639,7 +850,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 x_t0 = tok_match(len, (uint32_t)L.m_off[s] + 1);
                 x_next = s + len;
             } else {
-                x_t0 = in[pos];
+                x_t0 = *inp(pos);
                 x_next = s + 1;
             }
             x_ntoks = 1;
@@ -675,6 +886,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             __syncthreads();
             cur ^= 1;
         }
+        DT_MARK(3);
         // emit the tokens of marked slots in position order
         const bool live = tid < lim && L.mark[tid] != 0;
         const bool livex = tid == kCT - 1 && lim == kCT + 1 && L.mark[kCT] != 0;
@@ -716,13 +928,17 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.m_off[0] = L.m_off[kCT];
         }
         __syncthreads();
+        DT_MARK(4);
         // ---- close the block when it is large enough or the chunk ends -------------
         const uint32_t covered = L.entry;   // every byte below is inside an emitted token
         if (tail || covered - L.block_start >= kBlockSoft || L.block_ntok + 2 * kCT + 2 > kTokCap) {
             const uint32_t block_end = tail ? n : covered;
             flush_block(L, in, block_end, tail && last_chunk, tok, out_words);
         }
+        DT_MARK(5);
     }
+    if (RSX_DEV_TIMERS && tid == 0)
+        for (int k = 0; k < 6; k++) atomicAdd(&g_deflate_t[k], dt[k]);
 
     // chunk trailer: sync flush between chunks (src/compress/mod.rs:662-681)
     if (tid == 0) {
@@ -917,6 +1133,17 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     (void)hipEventRecord(e->ev_end, e->stream);
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
+    if (RSX_DEV_TIMERS && getenv("RSX_DEFLATE_STATS")) {
+        unsigned long long t[12];
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+        RSX_HIP(e, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_deflate_t), sizeof t));
+        fprintf(stderr, "[deflate] cycles/chunk: slide %.0f insert %.0f search %.0f parse %.0f emit %.0f flush %.0f (codes %.0f header %.0f)\n",
+                t[0] / (double)chunks, t[1] / (double)chunks, t[2] / (double)chunks, t[3] / (double)chunks,
+                t[4] / (double)chunks, t[5] / (double)chunks, t[6] / (double)chunks, t[7] / (double)chunks);
+        fprintf(stderr, "[deflate] chain steps: lane total %llu, 64 x wave max %llu\n", t[8], t[9]);
+        unsigned long long z[12] = {0};
+        RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_deflate_t), z, sizeof z));
+    }
     if (format != RSX_FORMAT_DEFLATE) {
         int kind = format == RSX_FORMAT_GZIP ? RSX_CHECKSUM_CRC32 : RSX_CHECKSUM_ADLER32;
         int r = checksum_launch(e, kind, format == RSX_FORMAT_GZIP ? 0u : 1u, in, in_off, nullptr, n,
