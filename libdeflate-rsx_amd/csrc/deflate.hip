@@ -39,14 +39,14 @@
 
 namespace {
 
-constexpr int kCT = 512;                        // threads per chunk
+constexpr int kCT = 1024;                       // threads per chunk
 constexpr uint32_t kChunk = 256 * 1024;         // src/compress/mod.rs:699-700
 constexpr int kHashBits = 13;                   // 32-bit LDS exchange words: 2^13 heads = 32 KiB
                                                 // (the reference hashes to 15 bits, matchfinder.rs:784)
 constexpr int kHash3Bits = 11;
 constexpr uint32_t kMaxDist3 = 4096;           // farthest match of length 3 worth its offset bits
 constexpr uint32_t kWindow = 32768;
-constexpr uint32_t kBlockSoft = 65535 - 512 - 300;  // close the block once it holds this many bytes
+constexpr uint32_t kBlockSoft = 65535 - kCT - 300;  // close the block once it holds this many bytes
 constexpr uint32_t kTokCap = 66 * 1024;         // tokens per block (<= bytes per block)
 constexpr uint32_t kScratchPad = 256;           // chunk scratch = chunk_len + kScratchPad
 // LDS copy of the input around the current batch: 32 KiB of history, the batch, and
@@ -117,10 +117,14 @@ struct __align__(16) ChunkLds {
     uint32_t block_start;     // chunk position where the open block starts
     uint32_t next_entry;      // scratch for the parse hand-over
     uint64_t out_bits;        // bits written to the chunk output so far
-    uint32_t body_bits_lo;
-    uint32_t block_mode;      // 2 dynamic, 0 stored
     uint32_t huff_scratch[288 + 32];
     uint32_t len_counts[2][16];
+    uint32_t huff_flag[2];           // an alphabet needs the length-limiting walk
+    uint32_t pre_freq[19], pre_code[19];
+    uint8_t pre_len[20];
+    uint32_t nl, no, np;             // code lengths sent per alphabet
+    uint32_t body_bits;
+    unsigned long long run_mask[5];  // first lanes of the runs of equal code lengths
 };
 
 // ---- bit output: the chunk scratch is zeroed up front, every write is an OR ----
@@ -136,155 +140,62 @@ __device__ inline void or_bits(uint32_t *words, uint64_t bitpos, uint64_t value,
     if (sh + nbits > 32) atomicOr(&words[w + 1], (uint32_t)(v >> 32));
 }
 
-// ---- Huffman code construction, one lane (src/compress/huffman_comp.rs) ----------
+// ---- Huffman code construction (src/compress/huffman_comp.rs) spread over the workgroup ----
+// Sorting, node depths, length assignment and codeword numbering are data parallel; the
+// two-queue tree build (huffman_comp.rs:38-62) stays on one lane per alphabet, and so does
+// the length-limiting walk (huffman_comp.rs:64-89) in the rare case a code exceeds max_len.
 
 constexpr uint32_t kSymBits = 10;
 constexpr uint32_t kSymMask = (1u << kSymBits) - 1;
-constexpr uint32_t kFreqMask = ~kSymMask;
 
 __device__ inline uint32_t reverse_bits(uint32_t c, uint32_t len) { return __brev(c) >> (32 - len); }
 
-// lens[] / codes[] for num_syms <= 32 symbols; a = scratch of num_syms words.
-__device__ __noinline__ void make_huffman_code(uint32_t num_syms, uint32_t max_len,
-                                               const uint32_t *freqs, uint8_t *lens, uint32_t *codes,
-                                               uint32_t *a)
+// one lane: a[0..used) sorted (freq << 10 | sym) -> a[node] = parent << 10 | sym for the
+// internal nodes 0..used-3 (node used-2 is the root).  The heads of the leaf queue and of
+// the node queue are cached in registers, so an iteration costs one round of LDS reads.
+__device__ __noinline__ void huff_build_tree(uint32_t *a, uint32_t used)
 {
-    // sort_symbols (huffman_comp.rs:8-36): counting sort on min(freq, num_syms-1), then the
-    // last bucket by full key
-    uint32_t counters[32];
-    for (uint32_t i = 0; i < num_syms; i++) counters[i] = 0;
-    for (uint32_t s = 0; s < num_syms; s++) {
-        uint32_t f = freqs[s] < num_syms - 1 ? freqs[s] : num_syms - 1;
-        counters[f]++;
-    }
-    uint32_t pos = 0;
-    for (uint32_t i = 1; i < num_syms; i++) {
-        uint32_t c = counters[i];
-        counters[i] = pos;
-        pos += c;
-    }
-    const uint32_t used = pos;
-    for (uint32_t s = 0; s < num_syms; s++) {
-        uint32_t f = freqs[s];
-        if (f) {
-            uint32_t b = f < num_syms - 1 ? f : num_syms - 1;
-            a[counters[b]++] = s | (f << kSymBits);
+    const uint32_t last = used - 1;
+    uint32_t i = 0, b = 0, e = 0;
+    uint32_t li0 = a[0] >> kSymBits, li1 = a[1] >> kSymBits;   // freq of leaves i, i + 1
+    uint32_t wb0 = 0, wb1 = 0;                                 // words of nodes b, b + 1
+    while (e < last) {
+        uint32_t nf;
+        const uint32_t we = a[e];
+        if (i < last && (b == e || li1 <= (wb0 >> kSymBits))) {
+            nf = li0 + li1;
+            i += 2;
+            li0 = i <= last ? a[i] >> kSymBits : 0;
+            li1 = i + 1 <= last ? a[i + 1] >> kSymBits : 0;
+        } else if (b + 2 <= e && (i > last || (wb1 >> kSymBits) < li0)) {
+            nf = (wb0 >> kSymBits) + (wb1 >> kSymBits);
+            a[b] = (e << kSymBits) | (wb0 & kSymMask);
+            a[b + 1] = (e << kSymBits) | (wb1 & kSymMask);
+            b += 2;
+            wb0 = b < e ? a[b] : 0;
+            wb1 = b + 1 < e ? a[b + 1] : 0;
         } else {
-            lens[s] = 0;
+            nf = li0 + (wb0 >> kSymBits);
+            a[b] = (e << kSymBits) | (wb0 & kSymMask);
+            i += 1;
+            b += 1;
+            li0 = li1;
+            li1 = i + 1 <= last ? a[i + 1] >> kSymBits : 0;
+            wb0 = wb1;
+            wb1 = b + 1 < e ? a[b + 1] : 0;
         }
-    }
-    {
-        uint32_t hs = counters[num_syms - 2], he = counters[num_syms - 1];
-        for (uint32_t i = hs + 1; i < he; i++) {  // insertion sort of the high-frequency tail
-            uint32_t v = a[i];
-            uint32_t j = i;
-            while (j > hs && a[j - 1] > v) {
-                a[j] = a[j - 1];
-                j--;
-            }
-            a[j] = v;
-        }
-    }
-    for (uint32_t s = 0; s < num_syms; s++) codes[s] = 0;
-    if (used < 2) {
-        // huffman_comp.rs:133-145: two 1-bit codes so the code is complete
-        uint32_t sym = used ? (a[0] & kSymMask) : 0;
-        uint32_t nz = sym ? sym : 1;
-        codes[0] = 0;
-        lens[0] = 1;
-        codes[nz] = 1;
-        lens[nz] = 1;
-        return;
-    }
-    // build_tree (huffman_comp.rs:38-62)
-    {
-        uint32_t last = used - 1, i = 0, b = 0, e = 0;
-        while (e < last) {
-            uint32_t nf;
-            if (i < last && (b == e || (a[i + 1] & kFreqMask) <= (a[b] & kFreqMask))) {
-                nf = (a[i] & kFreqMask) + (a[i + 1] & kFreqMask);
-                i += 2;
-            } else if (b + 2 <= e && (i > last || (a[b + 1] & kFreqMask) < (a[i] & kFreqMask))) {
-                nf = (a[b] & kFreqMask) + (a[b + 1] & kFreqMask);
-                a[b] = (e << kSymBits) | (a[b] & kSymMask);
-                a[b + 1] = (e << kSymBits) | (a[b + 1] & kSymMask);
-                b += 2;
-            } else {
-                nf = (a[i] & kFreqMask) + (a[b] & kFreqMask);
-                a[b] = (e << kSymBits) | (a[b] & kSymMask);
-                i += 1;
-                b += 1;
-            }
-            a[e] = nf | (a[e] & kSymMask);
-            e++;
-        }
-    }
-    // compute_length_counts (huffman_comp.rs:64-89)
-    uint32_t len_counts[16];
-    for (uint32_t l = 0; l <= max_len; l++) len_counts[l] = 0;
-    len_counts[1] = 2;
-    {
-        const uint32_t root = used - 2;
-        a[root] &= kSymMask;
-        for (int node = (int)root - 1; node >= 0; node--) {
-            uint32_t parent = a[node] >> kSymBits;
-            uint32_t depth = (a[parent] >> kSymBits) + 1;
-            a[node] = (a[node] & kSymMask) | (depth << kSymBits);
-            if (depth >= max_len) {
-                depth = max_len - 1;
-                while (len_counts[depth] == 0) depth--;
-            }
-            len_counts[depth]--;
-            len_counts[depth + 1] += 2;
-        }
-    }
-    // gen_codewords (huffman_comp.rs:95-123)
-    {
-        uint32_t i = 0;
-        for (uint32_t len = max_len; len >= 1; len--)
-            for (uint32_t c = len_counts[len]; c > 0; c--) lens[a[i++] & kSymMask] = (uint8_t)len;
-        uint32_t next[16];
-        next[0] = 0;
-        next[1] = 0;
-        for (uint32_t len = 2; len <= max_len; len++) next[len] = (next[len - 1] + len_counts[len - 1]) << 1;
-        for (uint32_t s = 0; s < num_syms; s++)
-            if (lens[s]) codes[s] = reverse_bits(next[lens[s]]++, lens[s]);
+        const uint32_t nw = (nf << kSymBits) | (we & kSymMask);
+        a[e] = nw;
+        if (b == e) wb0 = nw;
+        else if (b + 1 == e) wb1 = nw;
+        e++;
     }
 }
 
-
-// ---- the same construction spread over the workgroup --------------------------------
-// Sorting, length assignment and codeword numbering are data parallel; only the
-// two-queue tree build and the length-limiting walk (huffman_comp.rs:38-89) stay on one
-// lane, and the literal/length and offset alphabets run them on two different waves.
-
-// one lane: a[0..used) sorted (freq << 10 | sym) -> len_counts[1..max_len]; a[] keeps the
-// symbols in its low bits
-__device__ __noinline__ void huff_tree_serial(uint32_t *a, uint32_t used, uint32_t max_len,
-                                              uint32_t *len_counts)
+// one lane: the walk of huffman_comp.rs:64-89 with its length limiting
+__device__ __noinline__ void huff_limit_lengths(uint32_t *a, uint32_t used, uint32_t max_len,
+                                                uint32_t *len_counts)
 {
-    {
-        uint32_t last = used - 1, i = 0, b = 0, e = 0;
-        while (e < last) {
-            uint32_t nf;
-            if (i < last && (b == e || (a[i + 1] & kFreqMask) <= (a[b] & kFreqMask))) {
-                nf = (a[i] & kFreqMask) + (a[i + 1] & kFreqMask);
-                i += 2;
-            } else if (b + 2 <= e && (i > last || (a[b + 1] & kFreqMask) < (a[i] & kFreqMask))) {
-                nf = (a[b] & kFreqMask) + (a[b + 1] & kFreqMask);
-                a[b] = (e << kSymBits) | (a[b] & kSymMask);
-                a[b + 1] = (e << kSymBits) | (a[b + 1] & kSymMask);
-                b += 2;
-            } else {
-                nf = (a[i] & kFreqMask) + (a[b] & kFreqMask);
-                a[b] = (e << kSymBits) | (a[b] & kSymMask);
-                i += 1;
-                b += 1;
-            }
-            a[e] = nf | (a[e] & kSymMask);
-            e++;
-        }
-    }
     for (uint32_t l = 0; l < 16; l++) len_counts[l] = 0;
     len_counts[1] = 2;
     const uint32_t root = used - 2;
@@ -302,22 +213,16 @@ __device__ __noinline__ void huff_tree_serial(uint32_t *a, uint32_t used, uint32
     }
 }
 
-// All lanes: codes of the literal/length alphabet (lanes 0..287 hold its symbols) and the
-// offset alphabet (lanes 320..351) of the open block.
-__device__ void build_block_codes(ChunkLds &L)
+// All lanes call; lanes with `on` hold symbol `sym` of an alphabet described by the other
+// arguments (several alphabets may be built by disjoint lane groups of one call; a group
+// must not straddle the alphabet's lanes over non-participating ones).  pj = 2 * num_syms
+// words of scratch, flag = one word of scratch per alphabet, largest_alphabet = the same
+// value on every lane: the most symbols any alphabet of this call has.
+__device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32_t max_len,
+                                const uint32_t *freq, uint8_t *lens, uint32_t *codes, uint32_t *a,
+                                uint32_t *len_counts, uint32_t *pj, uint32_t *flag,
+                                uint32_t largest_alphabet)
 {
-    const uint32_t tid = threadIdx.x;
-    const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
-    const uint32_t sym = is_ll ? tid : tid - 320;
-    const uint32_t num_syms = is_ll ? 288u : 32u;
-    const uint32_t max_len = is_ll ? 14u : 15u;
-    const uint32_t *freq = is_ll ? L.litlen_freq : L.off_freq;
-    uint8_t *lens = is_ll ? L.litlen_len : L.off_len;
-    uint32_t *codes = is_ll ? L.litlen_code : L.off_code;
-    uint32_t *a = is_ll ? L.huff_scratch : L.huff_scratch + 288;
-    uint32_t *len_counts = is_ll ? L.len_counts[0] : L.len_counts[1];
-    const bool on = is_ll || is_off;
-
     // rank sort on (freq, sym) == the order of huffman_comp.rs:8-36
     uint32_t used = 0;
     if (on) {
@@ -331,6 +236,8 @@ __device__ void build_block_codes(ChunkLds &L)
         codes[sym] = 0;
         lens[sym] = 0;
         if (f) a[rank] = key;
+        if (sym < 16) len_counts[sym] = sym == 1 ? 2 : 0;
+        if (sym == 0) *flag = 0;
     }
     __syncthreads();
     if (on && sym == 0) {
@@ -343,12 +250,40 @@ __device__ void build_block_codes(ChunkLds &L)
             codes[nz] = 1;
             lens[nz] = 1;
         } else {
-            huff_tree_serial(a, used, max_len, len_counts);
+            huff_build_tree(a, used);
         }
     }
     __syncthreads();
+    // depth of the internal nodes by pointer jumping: word = depth << 16 | ancestor
+    const bool tree = on && used >= 2;
+    const uint32_t root = used - 2;
+    const bool node = tree && sym <= root;
+    if (node) pj[sym] = sym == root ? root : ((1u << 16) | (a[sym] >> kSymBits));
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t span = 1; span < largest_alphabet; span <<= 1) {   // same trip count on all lanes
+        if (node) {
+            const uint32_t w = pj[cur + sym], up = pj[cur + (w & 0xFFFF)];
+            pj[(cur ^ num_syms) + sym] = ((w & 0xFFFF0000u) + (up & 0xFFFF0000u)) | (up & 0xFFFF);
+        }
+        __syncthreads();
+        cur ^= num_syms;
+    }
+    // without an over-long code, len_counts is the histogram the walk would produce
+    if (node && sym != root) {
+        const uint32_t depth = pj[cur + sym] >> 16;
+        if (depth >= max_len) {
+            atomicOr(flag, 1u);
+        } else {
+            atomicSub(&len_counts[depth], 1u);
+            atomicAdd(&len_counts[depth + 1], 2u);
+        }
+    }
+    __syncthreads();
+    if (tree && sym == 0 && *flag) huff_limit_lengths(a, used, max_len, len_counts);
+    __syncthreads();
     // gen_codewords (huffman_comp.rs:95-123): sorted index i takes the longest lengths first
-    if (on && used >= 2 && sym < used) {
+    if (tree && sym < used) {
         uint32_t c = 0, len = max_len;
         for (; len >= 1; len--) {
             c += len_counts[len];
@@ -357,7 +292,7 @@ __device__ void build_block_codes(ChunkLds &L)
         lens[a[sym] & kSymMask] = (uint8_t)len;
     }
     __syncthreads();
-    if (on && used >= 2) {
+    if (tree) {
         const uint32_t len = lens[sym];
         if (len) {
             uint32_t next = 0;
@@ -367,114 +302,6 @@ __device__ void build_block_codes(ChunkLds &L)
         }
     }
     __syncthreads();
-}
-
-// One lane: block type decision and the block
-// header (src/compress/mod.rs:1375-1398, :1775-1883).  Returns through L.block_mode.
-__device__ __noinline__ void begin_block(ChunkLds &L, uint32_t *out_words, uint32_t block_bytes,
-                                         bool is_final)
-{
-
-    // code-length sequence and its run-length items (mod.rs:1790-1839)
-    uint32_t nl = 288, no = 32;
-    while (nl > 257 && L.litlen_len[nl - 1] == 0) nl--;
-    while (no > 1 && L.off_len[no - 1] == 0) no--;
-    const uint32_t total = nl + no;
-    auto len_at = [&](uint32_t i) -> uint32_t { return i < nl ? L.litlen_len[i] : L.off_len[i - nl]; };
-    uint16_t *items = reinterpret_cast<uint16_t *>(L.huff_scratch);  // <= 320 items
-    uint32_t nitems = 0;
-    uint32_t pre_freq[19];
-    for (int i = 0; i < 19; i++) pre_freq[i] = 0;
-    for (uint32_t i = 0; i < total;) {
-        uint32_t len = len_at(i), run = 1;
-        while (i + run < total && len_at(i + run) == len) run++;
-        const uint32_t total_run = run;
-        if (len == 0) {
-            while (run >= 11) {
-                uint32_t k = run < 138 ? run : 138;
-                items[nitems++] = (uint16_t)((18 << 8) | (k - 11));
-                pre_freq[18]++;
-                run -= k;
-            }
-            if (run >= 3) {
-                uint32_t k = run < 10 ? run : 10;
-                items[nitems++] = (uint16_t)((17 << 8) | (k - 3));
-                pre_freq[17]++;
-                run -= k;
-            }
-        } else if (run >= 4) {
-            items[nitems++] = (uint16_t)(len << 8);
-            pre_freq[len]++;
-            run--;
-            while (run >= 3) {
-                uint32_t k = run < 6 ? run : 6;
-                items[nitems++] = (uint16_t)((16 << 8) | (k - 3));
-                pre_freq[16]++;
-                run -= k;
-            }
-        }
-        while (run > 0) {
-            items[nitems++] = (uint16_t)(len << 8);
-            pre_freq[len]++;
-            run--;
-        }
-        i += total_run;
-    }
-    uint8_t pre_len[19];
-    uint32_t pre_code[19];
-    uint32_t pre_scratch[19];
-    make_huffman_code(19, 7, pre_freq, pre_len, pre_code, pre_scratch);
-    uint32_t np = 19;
-    while (np > 4 && pre_len[k_precode_perm[np - 1]] == 0) np--;
-
-    // size of the block as a dynamic block vs. stored
-    uint64_t hdr_bits = 3 + 5 + 5 + 4 + 3 * np;
-    for (uint32_t j = 0; j < nitems; j++) {
-        uint32_t sym = items[j] >> 8;
-        hdr_bits += pre_len[sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
-    }
-    uint64_t body_bits = 0;
-    for (uint32_t s = 0; s < 286; s++) {
-        uint32_t extra = s >= 257 ? k_len_extra[s - 257] : 0;
-        body_bits += (uint64_t)L.litlen_freq[s] * (L.litlen_len[s] + extra);
-    }
-    for (uint32_t s = 0; s < 30; s++) body_bits += (uint64_t)L.off_freq[s] * (L.off_len[s] + k_off_extra[s]);
-    const uint64_t pos = L.out_bits;
-    const uint64_t stored_bits = (((pos + 3 + 7) & ~7ull) - pos) + 32 + 8ull * block_bytes;
-    if (block_bytes <= 65535 && stored_bits <= hdr_bits + body_bits) {
-        // stored block (src/compress/mod.rs:1408-1448): header bits, align, LEN, NLEN
-        or_bits(out_words, pos, is_final ? 1 : 0, 3);
-        uint64_t p = (pos + 3 + 7) & ~7ull;
-        or_bits(out_words, p, block_bytes, 16);
-        or_bits(out_words, p + 16, (~block_bytes) & 0xFFFF, 16);
-        L.out_bits = p + 32;
-        L.block_mode = 0;
-        return;
-    }
-    uint64_t p = pos;
-    or_bits(out_words, p, (is_final ? 1 : 0) | (2 << 1), 3);
-    p += 3;
-    or_bits(out_words, p, nl - 257, 5);
-    p += 5;
-    or_bits(out_words, p, no - 1, 5);
-    p += 5;
-    or_bits(out_words, p, np - 4, 4);
-    p += 4;
-    for (uint32_t j = 0; j < np; j++) {
-        or_bits(out_words, p, pre_len[k_precode_perm[j]], 3);
-        p += 3;
-    }
-    for (uint32_t j = 0; j < nitems; j++) {
-        uint32_t sym = items[j] >> 8, extra = items[j] & 0xFF;
-        or_bits(out_words, p, pre_code[sym], pre_len[sym]);
-        p += pre_len[sym];
-        uint32_t xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-        or_bits(out_words, p, extra, xb);
-        p += xb;
-    }
-    L.out_bits = p;
-    L.body_bits_lo = (uint32_t)body_bits;
-    L.block_mode = 2;
 }
 
 // bits of one token under the open block's codes
@@ -515,39 +342,180 @@ __device__ inline uint32_t wg_exclusive_scan(ChunkLds &L, uint32_t v, uint32_t *
     return before + x - v;
 }
 
-// All lanes: write the open block (header by lane 0, tokens by everyone) and reset
-// the block state.  in = chunk input, tok = this workgroup's token buffer.
+// the run-length items of `run` equal code lengths `len` (mod.rs:1790-1839)
+template <class F>
+__device__ inline void rle_run(uint32_t len, uint32_t run, F &&put)
+{
+    if (len == 0) {
+        while (run >= 11) {
+            uint32_t k = run < 138 ? run : 138;
+            put(18u, k - 11);
+            run -= k;
+        }
+        if (run >= 3) {
+            uint32_t k = run < 10 ? run : 10;
+            put(17u, k - 3);
+            run -= k;
+        }
+    } else if (run >= 4) {
+        put(len, 0u);
+        run--;
+        while (run >= 3) {
+            uint32_t k = run < 6 ? run : 6;
+            put(16u, k - 3);
+            run -= k;
+        }
+    }
+    while (run > 0) {
+        put(len, 0u);
+        run--;
+    }
+}
+
+__device__ inline uint32_t precode_extra_bits(uint32_t sym) { return sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0; }
+
+// All lanes: Huffman codes of the open block, the block type decision (src/compress/mod.rs:
+// 1375-1398), its header (mod.rs:1775-1883), the tokens, and a fresh block state.
+// in = chunk input, tok = this workgroup's token buffer.
 __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, bool is_final,
                             const uint32_t *tok, uint32_t *out_words)
 {
-    const int tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t ntok = L.block_ntok;
     const uint32_t bstart = L.block_start;
     const uint32_t block_bytes = block_end - bstart;
-    if (tid == 0) L.litlen_freq[256] = 1;  // end of block
+    // scratch over the parse tables, which are idle here
+    uint32_t *pj = reinterpret_cast<uint32_t *>(L.jump);               // [0, 640): node depths
+    uint16_t *items = reinterpret_cast<uint16_t *>(pj + 640);          // <= 320 run-length items
+    static_assert(sizeof(L.jump) >= (640 + 160) * 4, "scratch for the block header");
+    if (tid == 0) {
+        L.litlen_freq[256] = 1;  // end of block
+        L.nl = 257;
+        L.no = 1;
+        L.np = 4;
+        L.body_bits = 0;
+    }
+    if (tid < 19) L.pre_freq[tid] = 0;
     __syncthreads();
     unsigned long long fq = RSX_DEV_TIMERS ? clock64() : 0;
-    build_block_codes(L);
+    const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
+    const uint32_t osym = tid - 320;
+    huff_collective(is_ll || is_off, is_ll ? tid : osym, is_ll ? 288u : 32u, is_ll ? 14u : 15u,
+                    is_ll ? L.litlen_freq : L.off_freq, is_ll ? L.litlen_len : L.off_len,
+                    is_ll ? L.litlen_code : L.off_code, is_ll ? L.huff_scratch : L.huff_scratch + 288,
+                    is_ll ? L.len_counts[0] : L.len_counts[1], is_ll ? pj : pj + 576,
+                    is_ll ? &L.huff_flag[0] : &L.huff_flag[1], 288u);
     if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[6], t_ - fq); fq = t_; }
-    if (tid == 0) begin_block(L, out_words, block_bytes, is_final);
+
+    // ---- lengths to send, cost of the body ------------------------------------------
+    {
+        uint32_t bb = 0;
+        if (is_ll) {
+            const uint32_t l = L.litlen_len[tid];
+            if (l) atomicMax(&L.nl, tid + 1);
+            if (tid < 286) bb = L.litlen_freq[tid] * (l + (tid >= 257 ? k_len_extra[tid - 257] : 0));
+        } else if (is_off) {
+            const uint32_t l = L.off_len[osym];
+            if (l) atomicMax(&L.no, osym + 1);
+            if (osym < 30) bb = L.off_freq[osym] * (l + k_off_extra[osym]);
+        }
+        for (int o = 32; o; o >>= 1) bb += __shfl_xor(bb, o);
+        if ((tid & 63) == 0 && bb) atomicAdd(&L.body_bits, bb);
+    }
     __syncthreads();
+    const uint32_t nl = L.nl, no = L.no, total = nl + no;
+    auto len_at = [&](uint32_t i) -> uint32_t { return i < nl ? L.litlen_len[i] : L.off_len[i - nl]; };
+    // ---- run-length items: the first lane of every run of equal lengths writes them ----
+    uint32_t mylen = 0;
+    bool start = false;
+    if (tid < total) {
+        mylen = len_at(tid);
+        start = tid == 0 || len_at(tid - 1) != mylen;
+    }
+    {
+        const unsigned long long bal = __ballot(start);
+        if ((tid & 63) == 0 && tid < 320) L.run_mask[tid >> 6] = bal;
+    }
+    __syncthreads();
+    uint32_t run = 0, cnt = 0;
+    if (start) {
+        uint32_t nxt = total;
+        const uint32_t w = tid >> 6;
+        const unsigned long long m = (L.run_mask[w] >> (tid & 63)) >> 1;
+        if (m) {
+            nxt = tid + 1 + (uint32_t)(__ffsll((long long)m) - 1);
+        } else {
+            for (uint32_t w2 = w + 1; w2 < 5; w2++) {
+                const unsigned long long m2 = L.run_mask[w2];
+                if (m2) {
+                    nxt = w2 * 64 + (uint32_t)(__ffsll((long long)m2) - 1);
+                    break;
+                }
+            }
+        }
+        run = nxt - tid;
+        rle_run(mylen, run, [&](uint32_t, uint32_t) { cnt++; });
+    }
+    uint32_t nitems;
+    uint32_t ioff = wg_exclusive_scan(L, cnt, &nitems);
+    if (start)
+        rle_run(mylen, run, [&](uint32_t sym, uint32_t extra) {
+            items[ioff++] = (uint16_t)((sym << 8) | extra);
+            atomicAdd(&L.pre_freq[sym], 1u);
+        });
+    __syncthreads();
+    // ---- precode -----------------------------------------------------------------------
+    huff_collective(tid < 19, tid, 19u, 7u, L.pre_freq, L.pre_len, L.pre_code, L.huff_scratch,
+                    L.len_counts[0], pj, &L.huff_flag[0], 19u);
+    if (tid < 19 && L.pre_len[k_precode_perm[tid]]) atomicMax(&L.np, tid + 1);
+    uint32_t it = 0, ibits = 0;
+    if (tid < nitems) {
+        it = items[tid];
+        ibits = L.pre_len[it >> 8] + precode_extra_bits(it >> 8);
+    }
+    uint32_t items_bits;
+    const uint32_t ipos = wg_exclusive_scan(L, ibits, &items_bits);
+    const uint32_t np = L.np;
+    const uint64_t hdr_bits = 3 + 5 + 5 + 4 + 3 * np + items_bits;
+    const uint64_t body_bits = L.body_bits;
+    const uint64_t pos = L.out_bits;
+    const uint64_t stored_bits = (((pos + 3 + 7) & ~7ull) - pos) + 32 + 8ull * block_bytes;
+    const bool stored = block_bytes <= 65535 && stored_bits <= hdr_bits + body_bits;
+    __syncthreads();   // everyone has read out_bits
     if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[7], t_ - fq); fq = t_; }
-    const uint64_t body0 = L.out_bits;
-    if (L.block_mode == 0) {
-        // stored: raw bytes behind LEN/NLEN (byte aligned)
-        uint8_t *ob = reinterpret_cast<uint8_t *>(out_words) + (body0 >> 3);
+    if (stored) {
+        // stored block (src/compress/mod.rs:1408-1448): header bits, align, LEN, NLEN, bytes
+        const uint64_t p = (pos + 3 + 7) & ~7ull;
+        if (tid == 0) {
+            or_bits(out_words, pos, is_final ? 1 : 0, 3);
+            or_bits(out_words, p, block_bytes, 16);
+            or_bits(out_words, p + 16, (~block_bytes) & 0xFFFF, 16);
+            L.out_bits = p + 32 + 8ull * block_bytes;
+        }
+        uint8_t *ob = reinterpret_cast<uint8_t *>(out_words) + ((p + 32) >> 3);
         for (uint32_t k = tid; k < block_bytes; k += kCT) ob[k] = in[bstart + k];
-        __syncthreads();
-        if (tid == 0) L.out_bits = body0 + 8ull * block_bytes;
     } else {
+        if (tid == 0) {
+            or_bits(out_words, pos, (is_final ? 1 : 0) | (2 << 1), 3);
+            or_bits(out_words, pos + 3, nl - 257, 5);
+            or_bits(out_words, pos + 8, no - 1, 5);
+            or_bits(out_words, pos + 13, np - 4, 4);
+        }
+        if (tid < np) or_bits(out_words, pos + 17 + 3 * tid, L.pre_len[k_precode_perm[tid]], 3);
+        if (tid < nitems) {
+            const uint32_t sym = it >> 8, l = L.pre_len[sym];
+            or_bits(out_words, pos + 17 + 3 * np + ipos, L.pre_code[sym] | ((it & 0xFF) << l),
+                    l + precode_extra_bits(sym));
+        }
+        const uint64_t body0 = pos + hdr_bits;
         // each lane packs a contiguous run of tokens
         const uint32_t per = (ntok + kCT - 1) / kCT;
         const uint32_t r0 = tid * per < ntok ? tid * per : ntok;
         const uint32_t r1 = r0 + per < ntok ? r0 + per : ntok;
         uint32_t bits = 0;
         for (uint32_t i = r0; i < r1; i++) bits += token_bits(L, tok[i]);
-        uint32_t total;
-        uint32_t off = wg_exclusive_scan(L, bits, &total);
+        uint32_t tbits;
+        uint32_t off = wg_exclusive_scan(L, bits, &tbits);
         uint64_t p = body0 + off;
         for (uint32_t i = r0; i < r1; i++) {
             uint32_t t = tok[i];
@@ -568,13 +536,13 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
                 p += l2 + k_off_extra[os];
             }
         }
-        __syncthreads();
         if (tid == 0) {
-            uint64_t e = body0 + total;
+            uint64_t e = body0 + tbits;
             or_bits(out_words, e, L.litlen_code[256], L.litlen_len[256]);
             L.out_bits = e + L.litlen_len[256];
         }
     }
+    __syncthreads();
     // reset the block state
     for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
     if (tid < 32) L.off_freq[tid] = 0;
@@ -752,7 +720,6 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             __syncthreads();
         }
         DT_MARK(1);
-        uint32_t stat_depth = 0;
         if (can && lp.max_depth) {
             // Walk the chain (matchfinder.rs:808-870).  Per candidate one round of LDS
             // reads (the link and 20 bytes of the candidate) decides lengths up to 20
@@ -768,7 +735,6 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             for (uint32_t depth = 0; depth < lp.max_depth; depth++) {
                 dist += link;
                 if (!alive || link == 0 || dist > max_dist) break;
-                if (RSX_DEV_TIMERS) stat_depth++;
                 const uint32_t cand = p - dist;
                 const uint8_t *m = inp(cand);
                 link = L.prev[cand & (kWindow - 1)];
@@ -793,13 +759,6 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 }
             }
         }
-#if RSX_DEV_TIMERS
-        {
-            uint32_t dsteps = stat_depth, m = dsteps, sum = dsteps;
-            for (int o = 32; o; o >>= 1) { uint32_t y = __shfl_xor(m, o); m = y > m ? y : m; sum += __shfl_xor(sum, o); }
-            if ((tid & 63) == 0) { atomicAdd(&g_deflate_t[8], (unsigned long long)sum); atomicAdd(&g_deflate_t[9], (unsigned long long)m * 64); }
-        }
-#endif
         L.m_len[tid + 1] = (uint16_t)best_len;
         L.m_off[tid + 1] = (uint16_t)(best_off - (best_off ? 1 : 0));  // dist-1 fits 15 bits
         __syncthreads();
@@ -1140,7 +1099,6 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
         fprintf(stderr, "[deflate] cycles/chunk: slide %.0f insert %.0f search %.0f parse %.0f emit %.0f flush %.0f (codes %.0f header %.0f)\n",
                 t[0] / (double)chunks, t[1] / (double)chunks, t[2] / (double)chunks, t[3] / (double)chunks,
                 t[4] / (double)chunks, t[5] / (double)chunks, t[6] / (double)chunks, t[7] / (double)chunks);
-        fprintf(stderr, "[deflate] chain steps: lane total %llu, 64 x wave max %llu\n", t[8], t[9]);
         unsigned long long z[12] = {0};
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_deflate_t), z, sizeof z));
     }
