@@ -148,12 +148,16 @@ __device__ inline void or_bits(uint32_t *words, uint64_t bitpos, uint64_t value,
 constexpr uint32_t kSymBits = 10;
 constexpr uint32_t kSymMask = (1u << kSymBits) - 1;
 
+// LDS words behind a non-inlined call: a plain pointer would make every access there a
+// flat one
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 __device__ inline uint32_t reverse_bits(uint32_t c, uint32_t len) { return __brev(c) >> (32 - len); }
 
 // one lane: a[0..used) sorted (freq << 10 | sym) -> a[node] = parent << 10 | sym for the
 // internal nodes 0..used-3 (node used-2 is the root).  The heads of the leaf queue and of
 // the node queue are cached in registers, so an iteration costs one round of LDS reads.
-__device__ __noinline__ void huff_build_tree(uint32_t *a, uint32_t used)
+__device__ __noinline__ void huff_build_tree(lds_u32 *a, uint32_t used)
 {
     const uint32_t last = used - 1;
     uint32_t i = 0, b = 0, e = 0;
@@ -193,8 +197,8 @@ __device__ __noinline__ void huff_build_tree(uint32_t *a, uint32_t used)
 }
 
 // one lane: the walk of huffman_comp.rs:64-89 with its length limiting
-__device__ __noinline__ void huff_limit_lengths(uint32_t *a, uint32_t used, uint32_t max_len,
-                                                uint32_t *len_counts)
+__device__ __noinline__ void huff_limit_lengths(lds_u32 *a, uint32_t used, uint32_t max_len,
+                                                lds_u32 *len_counts)
 {
     for (uint32_t l = 0; l < 16; l++) len_counts[l] = 0;
     len_counts[1] = 2;
@@ -250,7 +254,7 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
             codes[nz] = 1;
             lens[nz] = 1;
         } else {
-            huff_build_tree(a, used);
+            huff_build_tree((lds_u32 *)a, used);
         }
     }
     __syncthreads();
@@ -280,7 +284,7 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
         }
     }
     __syncthreads();
-    if (tree && sym == 0 && *flag) huff_limit_lengths(a, used, max_len, len_counts);
+    if (tree && sym == 0 && *flag) huff_limit_lengths((lds_u32 *)a, used, max_len, (lds_u32 *)len_counts);
     __syncthreads();
     // gen_codewords (huffman_comp.rs:95-123): sorted index i takes the longest lengths first
     if (tree && sym < used) {

@@ -121,6 +121,7 @@ struct HeaderScratch {
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
     uint8_t precode_lens[20];
+    uint32_t len_counts[16], offsets[16];   // working arrays of the table build
 };
 struct SpecScratch {
     uint32_t sub_start[kT];       // start handed to a sub-sequence that is re-decoded
@@ -159,14 +160,20 @@ struct __align__(16) StreamLds {
     uint64_t bitpos;      // next unread bit, relative to the start of the DEFLATE body
 };
 
+// The serial header code sits behind non-inlined calls.  Its LDS operands carry their
+// address space in the type: through plain pointers every access would be a flat one.
+#define RSX_LDS __attribute__((address_space(3)))
+typedef RSX_LDS StreamLds LdsStream;
+
 // Serial decode-table build; restates src/decompress/mod.rs:1324-1495 (called by
-// one thread).  Returns false when the code-length set is rejected.
-__device__ __noinline__ bool build_decode_table(uint32_t *table, const uint8_t *lens, uint32_t num_syms,
-                                   int kind, uint32_t table_bits, uint32_t max_codeword_len,
-                                   uint16_t *sorted_syms, uint32_t *table_bits_ret)
+// one thread).  Returns false when the code-length set is rejected.  len_counts and
+// offsets are 16 words of scratch each.
+__device__ __noinline__ bool build_decode_table(RSX_LDS uint32_t *table, const RSX_LDS uint8_t *lens,
+                                                uint32_t num_syms, int kind, uint32_t table_bits,
+                                                uint32_t max_codeword_len, RSX_LDS uint16_t *sorted_syms,
+                                                RSX_LDS uint32_t *table_bits_ret,
+                                                RSX_LDS uint32_t *len_counts, RSX_LDS uint32_t *offsets)
 {
-    uint32_t len_counts[16];
-    uint32_t offsets[16];
     for (int i = 0; i < 16; i++) len_counts[i] = 0;
     for (uint32_t s = 0; s < num_syms; s++) len_counts[lens[s]]++;
     while (max_codeword_len > 1 && len_counts[max_codeword_len] == 0) max_codeword_len--;
@@ -198,7 +205,7 @@ __device__ __noinline__ bool build_decode_table(uint32_t *table, const uint8_t *
         return true;
     }
 
-    const uint16_t *sp = sorted_syms + offsets[0];
+    const RSX_LDS uint16_t *sp = sorted_syms + offsets[0];
     uint32_t codeword = 0;
     uint32_t len = 1;
     while (len_counts[len] == 0) len++;
@@ -260,7 +267,8 @@ __device__ __noinline__ bool build_decode_table(uint32_t *table, const uint8_t *
 }
 
 // 32 valid bits starting at window bit offset b
-__device__ inline uint32_t fetch_bits(const uint32_t *win, uint32_t b)
+template <class WordPtr>
+__device__ inline uint32_t fetch_bits(WordPtr win, uint32_t b)
 {
     uint32_t w = b >> 5;
     uint64_t v = ((uint64_t)win[w + 1] << 32) | win[w];
@@ -316,7 +324,7 @@ __device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *w
 // and build the three tables.  Runs on one thread; reads bits through the
 // staged window, which the caller guarantees covers the whole header
 // (a header is at most 14 + 19*3 + 320*(7+7) bits < 600 bytes).
-__device__ __noinline__ int read_dynamic_header(StreamLds &L, uint32_t *bp, int64_t win_bit0, uint64_t end_bit)
+__device__ __noinline__ int read_dynamic_header(LdsStream &L, uint32_t *bp, int64_t win_bit0, uint64_t end_bit)
 {
     uint32_t b = *bp;
     auto avail = [&](uint32_t need) { return (uint64_t)(win_bit0 + b + need) <= end_bit; };
@@ -334,7 +342,7 @@ __device__ __noinline__ int read_dynamic_header(StreamLds &L, uint32_t *bp, int6
     }
     for (; i < 19; i++) L.hdr.precode_lens[c_precode_perm[i]] = 0;
     if (!build_decode_table(L.hdr.precode, L.hdr.precode_lens, 19, KIND_PRECODE, kPrecodeBits, 7,
-                            L.hdr.sorted_syms, nullptr))
+                            L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets))
         return RSX_BAD_DATA;
     const uint32_t total = num_litlen + num_offset;
     i = 0;
@@ -373,16 +381,16 @@ __device__ __noinline__ int read_dynamic_header(StreamLds &L, uint32_t *bp, int6
     }
     *bp = b;
     if (!build_decode_table(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
-                            L.hdr.sorted_syms, nullptr))
+                            L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets))
         return RSX_BAD_DATA;
     if (!build_decode_table(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
-                            L.hdr.sorted_syms, &L.litlen_tablebits))
+                            L.hdr.sorted_syms, &L.litlen_tablebits, L.hdr.len_counts, L.hdr.offsets))
         return RSX_BAD_DATA;
     return RSX_SUCCESS;
 }
 
 // src/decompress/mod.rs:355-401
-__device__ __noinline__ void load_static_codes(StreamLds &L)
+__device__ __noinline__ void load_static_codes(LdsStream &L)
 {
     uint32_t i = 0;
     for (; i < 144; i++) L.hdr.lens[i] = 8;
@@ -391,15 +399,15 @@ __device__ __noinline__ void load_static_codes(StreamLds &L)
     for (; i < 288; i++) L.hdr.lens[i] = 8;
     for (; i < 320; i++) L.hdr.lens[i] = 5;
     build_decode_table(L.offset, L.hdr.lens + 288, 32, KIND_OFFSET, kOffsetBits, 15, L.hdr.sorted_syms,
-                       nullptr);
+                       nullptr, L.hdr.len_counts, L.hdr.offsets);
     build_decode_table(L.litlen, L.hdr.lens, 288, KIND_LITLEN, kLitlenBits, 15, L.hdr.sorted_syms,
-                       &L.litlen_tablebits);
+                       &L.litlen_tablebits, L.hdr.len_counts, L.hdr.offsets);
 }
 
 // Thread-0 part of a round: when the stream is between blocks, read the next
 // block header from the staged window (src/decompress/mod.rs:225-252) and build
 // the decode tables.  Leaves L.in_block / L.stored_len / L.status / L.restage set.
-__device__ __noinline__ void header_step(StreamLds &L, const StreamCtx &c, int64_t win_bit0)
+__device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64_t win_bit0)
 {
     const uint64_t end_bit = c.body_len * 8;
     uint32_t b = (uint32_t)((int64_t)L.bitpos - win_bit0);
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
         if (!L.in_block) {
             STAT_BEGIN();
             __syncthreads();
-            if (tid == 0) header_step(L, c, win_bit0);
+            if (tid == 0) header_step(*(LdsStream *)&L, c, win_bit0);
             __syncthreads();
             STAT_END(tH);
         }
