@@ -520,25 +520,42 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
         for (uint32_t i = r0; i < r1; i++) bits += token_bits(L, tok[i]);
         uint32_t tbits;
         uint32_t off = wg_exclusive_scan(L, bits, &tbits);
-        uint64_t p = body0 + off;
-        for (uint32_t i = r0; i < r1; i++) {
-            uint32_t t = tok[i];
-            if (!(t & 0x80000000u)) {
-                uint32_t s = t & 0xFF;
-                or_bits(out_words, p, L.litlen_code[s], L.litlen_len[s]);
-                p += L.litlen_len[s];
-            } else {
-                uint32_t len = (t & 0xFF) + 3, dist = ((t >> 8) & 0x7FFF) + 1;
-                uint32_t ls = L.len_slot[len], os = offset_slot(dist);
-                uint32_t l1 = L.litlen_len[257 + ls];
-                or_bits(out_words, p, L.litlen_code[257 + ls] | ((len - k_len_base[ls]) << l1),
-                        l1 + k_len_extra[ls]);
-                p += l1 + k_len_extra[ls];
-                uint32_t l2 = L.off_len[os];
-                or_bits(out_words, p, L.off_code[os] | ((dist - k_off_base[os]) << l2),
-                        l2 + k_off_extra[os]);
-                p += l2 + k_off_extra[os];
+        // The lane owns every output word that lies wholly inside its run of bits and
+        // writes those with plain stores; only its first and last word can be shared with
+        // a neighbour (or the header) and are OR-ed in.
+        {
+            const uint64_t p = body0 + off;
+            uint32_t *wp = out_words + (p >> 5);
+            uint32_t nb = (uint32_t)(p & 31);   // bits below belong to someone else: stay 0 here
+            uint64_t acc = 0;
+            bool first = true;
+            auto put = [&](uint32_t code, uint32_t len) {
+                acc |= (uint64_t)code << nb;
+                nb += len;
+                if (nb >= 32) {
+                    if (first) atomicOr(wp, (uint32_t)acc);
+                    else *wp = (uint32_t)acc;
+                    first = false;
+                    wp++;
+                    acc >>= 32;
+                    nb -= 32;
+                }
+            };
+            for (uint32_t i = r0; i < r1; i++) {
+                const uint32_t t = tok[i];
+                if (!(t & 0x80000000u)) {
+                    const uint32_t s = t & 0xFF;
+                    put(L.litlen_code[s], L.litlen_len[s]);
+                } else {
+                    const uint32_t len = (t & 0xFF) + 3, dist = ((t >> 8) & 0x7FFF) + 1;
+                    const uint32_t ls = L.len_slot[len], os = offset_slot(dist);
+                    const uint32_t l1 = L.litlen_len[257 + ls];
+                    put(L.litlen_code[257 + ls] | ((len - k_len_base[ls]) << l1), l1 + k_len_extra[ls]);
+                    const uint32_t l2 = L.off_len[os];
+                    put(L.off_code[os] | ((dist - k_off_base[os]) << l2), l2 + k_off_extra[os]);
+                }
             }
+            if (acc) atomicOr(wp, (uint32_t)acc);
         }
         if (tid == 0) {
             uint64_t e = body0 + tbits;
