@@ -81,11 +81,15 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     """BASELINE.json configs[2]: batch zlib compress level 6, n x 1 MiB mixed text/binary."""
     import corpus
     import oracle_lib as orc
-    fmt, level = rsx.FORMAT_ZLIB, 6
+    level = args.level
+    fmt = rsx.FORMAT_ZLIB if args.corpus == "mixed" else rsx.FORMAT_DEFLATE
+    ofmt = orc.FMT_ZLIB if args.corpus == "mixed" else orc.FMT_DEFLATE
+    fmt_name = "zlib" if args.corpus == "mixed" else "raw deflate"
     buf = args.buf_kib * 1024
     n = args.streams
     distinct = min(args.distinct, n)
-    datas = [corpus.mixed(buf, 1000 * rank + i) for i in range(distinct)]
+    gen = {"mixed": corpus.mixed, "json": corpus.json_like, "text": corpus.text}[args.corpus]
+    datas = [gen(buf, 1000 * rank + i) for i in range(distinct)]
     h_in = np.frombuffer(b"".join(datas), dtype=np.uint8)
     d_one = torch.from_numpy(h_in.copy()).to(dev)
     d_in = d_one.repeat(n // distinct + 1)[: n * buf].contiguous()  # private copy per item
@@ -128,7 +132,7 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     ok = bool((st == 0).all())
     for i in range(distinct):  # the oracle must inflate every distinct stream to its input
         c = d_out[i * bound: i * bound + int(sz[i])].cpu().numpy().tobytes()
-        r, _, back = orc.decompress(c, buf, orc.FMT_ZLIB)
+        r, _, back = orc.decompress(c, buf, ofmt)
         ok = ok and r == 0 and back == datas[i]
     if not ok:
         raise SystemExit("bench.py: compressed output failed verification")
@@ -150,9 +154,10 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "batch zlib compress level 6, %d x %d KiB mixed text/binary per GPU"
-                                   % (n, args.buf_kib),
-                       "op": "compress", "format": "zlib", "level": level, "streams_per_gpu": n,
+            "config": {"workload": "batch %s compress level %d, %d x %d KiB %s per GPU"
+                                   % (fmt_name, level, n, args.buf_kib,
+                                      {"mixed": "mixed text/binary", "json": "JSON", "text": "text"}[args.corpus]),
+                       "op": "compress", "format": fmt_name, "level": level, "streams_per_gpu": n,
                        "buf_bytes": buf, "distinct_buffers": distinct,
                        "compressed_ratio": total_in / total_out, "verified": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -160,14 +165,14 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
                          "kernel": "deflate_chunks_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes": total_in + total_out},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and level <= 9:   # the restatement stops at level 9
             th = host_threads()
             flat = np.frombuffer(b"".join(datas), dtype=np.uint8)
             off = np.arange(distinct + 1, dtype=np.uint64) * np.uint64(buf)
             t1 = time.perf_counter()
             reps = 0
             while True:
-                _, _, csz, cst = orc.batch_compress(flat, off, orc.FMT_ZLIB, level, threads=th)
+                _, _, csz, cst = orc.batch_compress(flat, off, ofmt, level, threads=th)
                 reps += 1
                 cdt = time.perf_counter() - t1
                 if cdt >= 12.0:
@@ -190,6 +195,9 @@ def main():
     ap.add_argument("--buf-kib", type=int, default=1024, help="uncompressed KiB per stream")
     ap.add_argument("--distinct", type=int, default=64, help="distinct buffers generated on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--level", type=int, default=6, help="compress only")
+    ap.add_argument("--corpus", choices=["mixed", "json", "text"], default="mixed",
+                    help="compress only: mixed = zlib (headline), json/text = raw deflate")
     ap.add_argument("--op", choices=["decompress", "compress"], default="decompress",
                     help="decompress = gzip level-6 text (headline); compress = zlib level-6 mixed")
     args = ap.parse_args()

@@ -207,7 +207,7 @@ int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_
     if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
-    int r = ws_reserve(e, deflate_ws_bytes(n, total_in, max_item));
+    int r = ws_reserve(e, deflate_ws_bytes(n, total_in, max_item, level));
     if (r != RSX_OK) return r;
     return deflate_launch(e, format, level, in, in_off, n, total_in, max_item, out, out_off,
                           out_sizes, status);
@@ -239,7 +239,7 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
 
-    size_t kernel_ws = op == 0   ? deflate_ws_bytes(n, si.total, si.max_item)
+    size_t kernel_ws = op == 0   ? deflate_ws_bytes(n, si.total, si.max_item, level)
                        : op == 1 ? inflate_ws_bytes(n, so.total)
                                  : checksum_ws_bytes(n, si.total);
     size_t need = kernel_ws + align_up(si.total + 64, 256) + align_up(so.total + 64, 256) +

@@ -48,6 +48,11 @@ constexpr uint32_t kMaxDist3 = 4096;           // farthest match of length 3 wor
 constexpr uint32_t kWindow = 32768;
 constexpr uint32_t kBlockSoft = 65535 - kCT - 300;  // close the block once it holds this many bytes
 constexpr uint32_t kTokCap = 66 * 1024;         // tokens per block (<= bytes per block)
+constexpr uint32_t kPairs = 8;                  // recorded matches per position (levels 10-12)
+constexpr uint32_t kMaxBlocks = 8;              // blocks per chunk
+constexpr uint32_t kSegment = 8192;             // positions per piece of the cost-based parse (at least)
+constexpr uint32_t kMaxCuts = kChunk / kSegment + kMaxBlocks;
+static_assert(kChunk / kBlockSoft + 2 <= kMaxBlocks, "block list");
 constexpr uint32_t kScratchPad = 256;           // chunk scratch = chunk_len + kScratchPad
 // LDS copy of the input around the current batch: 32 KiB of history, the batch, and
 // the longest match behind it; slid forward kInSlide bytes at a time
@@ -70,18 +75,19 @@ __constant__ uint8_t k_precode_perm[19] = {16, 17, 18, 0, 8,  7, 9,  6, 10, 5,
 
 struct LevelParams {
     uint32_t max_depth, nice_len, lazy;
+    uint32_t optimal;   // levels 10-12: cost-based parse over all recorded matches
 };
 
-// src/compress/mod.rs:543-602 and :624-630.  Levels 10-12 use the deepest
-// hash-chain setting (the near-optimal parse is not built yet).
+// src/compress/mod.rs:543-602 and :624-630
 __host__ inline LevelParams level_params(int level)
 {
-    static const uint32_t depth[13] = {0, 2, 6, 12, 16, 16, 35, 100, 300, 600, 600, 600, 600};
-    static const uint32_t nice[13] = {0, 32, 10, 14, 30, 30, 65, 130, 258, 258, 258, 258, 258};
+    static const uint32_t depth[13] = {0, 2, 6, 12, 16, 16, 35, 100, 300, 600, 35, 100, 300};
+    static const uint32_t nice[13] = {0, 32, 10, 14, 30, 30, 65, 130, 258, 258, 75, 150, 258};
     LevelParams p;
     p.max_depth = depth[level];
     p.nice_len = nice[level];
     p.lazy = level >= 5 ? 1 : 0;
+    p.optimal = level >= 10 ? 1 : 0;
     return p;
 }
 
@@ -124,7 +130,9 @@ struct __align__(16) ChunkLds {
     uint8_t pre_len[20];
     uint32_t nl, no, np;             // code lengths sent per alphabet
     uint32_t body_bits;
-    unsigned long long run_mask[5];  // first lanes of the runs of equal code lengths
+    unsigned long long run_mask[5];
+    uint32_t blk_end[kMaxBlocks], nblk;   // block ends found by the first pass (levels 10-12)
+    uint32_t cut[kMaxCuts], ncut;         // ends of the pieces of the cost-based parse; bit 31 = also a block end  // first lanes of the runs of equal code lengths
 };
 
 // ---- bit output: the chunk scratch is zeroed up front, every write is an OR ----
@@ -600,6 +608,119 @@ __device__ inline uint32_t match_length(const uint8_t *a, const uint8_t *b, uint
     return n;
 }
 
+// ---- levels 10-12: cost-based parse (src/compress/mod.rs:1586-1773) --------------------
+// The reference runs a greedy pass for statistics, prices every symbol with the resulting
+// code lengths (update_costs, mod.rs:2209-2234) and then takes the cheapest path through
+// the matches its binary-tree matchfinder reports.  Here the first pass is the ordinary
+// batch loop, which also records for every position up to kPairs matches of increasing
+// length (nearest offset first), the pricing is the same, and the cheapest path is found
+// per piece of kSegment positions by one wave walking backwards: position i is the cheaper
+// of a literal and any prefix of any recorded match.  A second run of the batch loop
+// replays the chosen steps into tokens.
+
+constexpr uint32_t kBlkCostStride = 320;   // 288 literal/length + 32 offset code lengths
+
+// All lanes, first pass: close the block at block_end, keeping only its code lengths.
+__device__ void record_block(ChunkLds &L, uint32_t block_end, uint8_t *blkcost)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t *pj = reinterpret_cast<uint32_t *>(L.jump);
+    if (tid == 0) L.litlen_freq[256] = 1;
+    __syncthreads();
+    const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
+    const uint32_t osym = tid - 320;
+    huff_collective(is_ll || is_off, is_ll ? tid : osym, is_ll ? 288u : 32u, is_ll ? 14u : 15u,
+                    is_ll ? L.litlen_freq : L.off_freq, is_ll ? L.litlen_len : L.off_len,
+                    is_ll ? L.litlen_code : L.off_code, is_ll ? L.huff_scratch : L.huff_scratch + 288,
+                    is_ll ? L.len_counts[0] : L.len_counts[1], is_ll ? pj : pj + 576,
+                    is_ll ? &L.huff_flag[0] : &L.huff_flag[1], 288u);
+    const uint32_t k = L.nblk;
+    uint8_t *bc = blkcost + k * kBlkCostStride;
+    if (is_ll) bc[tid] = L.litlen_len[tid];
+    if (is_off) bc[288 + osym] = L.off_len[osym];
+    __syncthreads();
+    for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
+    if (tid < 32) L.off_freq[tid] = 0;
+    if (tid == 0) {
+        L.blk_end[k] = block_end;
+        L.nblk = k + 1;
+        L.cut[L.ncut++] = block_end | 0x80000000u;
+        L.block_ntok = 0;
+        L.block_start = block_end;
+    }
+    __syncthreads();
+}
+
+// One wave: cheapest path over positions [s, e) of a block whose code lengths are bc.
+// ws = 1024 words of LDS private to the wave.  mp[8 * i ..] = recorded matches of position
+// i on entry; mp[8 * i] = the chosen step (length 1 = literal) on return.
+__device__ void optimal_parse_piece(const ChunkLds &L, const uint8_t *in, uint32_t *mp, uint32_t s,
+                                    uint32_t e, const uint8_t *bc, uint32_t *ws)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *C = ws;                                          // cost to the end, ring of 512
+    uint8_t *litc = reinterpret_cast<uint8_t *>(ws + 512);     // [256]
+    uint8_t *lenc = litc + 256;                                // [260], index = match length
+    uint8_t *offc = lenc + 260;                                // [32], index = offset slot
+    for (uint32_t i = lane; i < 256; i += 64) {
+        const uint32_t l = bc[i];
+        litc[i] = (uint8_t)(l ? l : 13);
+    }
+    for (uint32_t l = 3 + lane; l <= 258; l += 64) {
+        const uint32_t ls = L.len_slot[l], cl = bc[257 + ls];
+        lenc[l] = (uint8_t)((cl ? cl : 13) + k_len_extra[ls]);
+    }
+    if (lane < 30) {
+        const uint32_t cl = bc[288 + lane];
+        offc[lane] = (uint8_t)((cl ? cl : 12) + k_off_extra[lane]);
+    }
+    if (lane == 0) C[e & 511] = 0;
+    const uint4 *pp = reinterpret_cast<const uint4 *>(mp);
+    uint4 na = pp[2 * (size_t)(e - 1)], nb = pp[2 * (size_t)(e - 1) + 1];
+    uint32_t nbyte = in[e - 1];
+    for (uint32_t i = e; i-- > s;) {
+        uint32_t q[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+        const uint32_t byte = nbyte;
+        if (i > s) {   // fetch the next position while this one is priced
+            na = pp[2 * (size_t)(i - 1)];
+            nb = pp[2 * (size_t)(i - 1) + 1];
+            nbyte = in[i - 1];
+        }
+        uint32_t max_len = 0;
+        bool valid = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            valid = valid && q[k] != 0;
+            q[k] = valid ? q[k] : 0;
+            max_len = valid ? (q[k] & 511) : max_len;
+        }
+        max_len = max_len < e - i ? max_len : e - i;
+        uint32_t best = ((litc[byte] + C[(i + 1) & 511]) << 9) | 1;
+        for (uint32_t base = 3; base <= max_len; base += 64) {
+            const uint32_t l = base + lane;
+            if (l <= max_len) {
+                uint32_t off1 = 0;
+#pragma unroll
+                for (int k = 7; k >= 0; k--) off1 = (q[k] & 511) >= l ? (q[k] >> 9) : off1;
+                const uint32_t cand = ((lenc[l] + offc[offset_slot(off1 + 1)] + C[(i + l) & 511]) << 9) | l;
+                best = cand < best ? cand : best;
+            }
+        }
+        for (int o = 32; o; o >>= 1) {
+            const uint32_t y = __shfl_xor(best, o);
+            best = y < best ? y : best;
+        }
+        const uint32_t len = best & 511;
+        uint32_t off1 = 0;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) off1 = (q[k] & 511) >= len ? (q[k] >> 9) : off1;
+        if (lane == 0) {
+            C[i & 511] = best >> 9;
+            mp[8 * (size_t)i] = len | (off1 << 9);
+        }
+    }
+}
+
 // Copy chunk positions [from, to) into the LDS input buffer with 16-byte units
 // aligned to the global address.  LDS index of chunk position p is p - w0 + phase.
 __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, uint32_t w0,
@@ -616,8 +737,10 @@ __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, u
 
 // Compress one chunk (<= 256 KiB) into `out_words` (zeroed, chunk_len + kScratchPad
 // bytes).  Returns the number of bytes written (uniform over the workgroup).
+// mp / blkcost: per-workgroup buffers of the cost-based parse (levels 10-12 only).
 __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, bool last_chunk,
-                                   LevelParams lp, uint32_t *tok, uint32_t *out_words)
+                                   LevelParams lp, uint32_t *tok, uint32_t *out_words, uint32_t *mp,
+                                   uint8_t *blkcost)
 {
     const int tid = threadIdx.x;
     // zero the output region (all later writes are ORs), reset the tables
@@ -641,6 +764,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.out_bits = 0;
             L.m_len[0] = 0;
             L.m_off[0] = 0;
+            L.nblk = 0;
+            L.ncut = 0;
         }
     }
     __syncthreads();
@@ -684,10 +809,47 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
 
     unsigned long long dt[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tq = RSX_DEV_TIMERS ? clock64() : 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += kCT) {
+    // Levels 10-12 run the batch loop twice: a first pass that searches, records the
+    // matches and the block ends, then (after the cost-based parse) a replay pass that
+    // turns the chosen steps into tokens block by block.
+    const uint32_t passes = lp.optimal && n ? 2 : 1;
+    for (uint32_t pass = 0; pass < passes; pass++) {
+    const bool analysis = lp.optimal && pass == 0, replay = pass == 1;
+    uint32_t blk = 0;
+    uint32_t n_eff = n;   // replay: end of the block being replayed
+    if (replay) {
+        __threadfence();
+        __syncthreads();
+        // pieces of all blocks, dealt round-robin to the waves; the hash tables are idle now
+        {
+            const uint32_t wave = tid >> 6;
+            uint32_t *ws = reinterpret_cast<uint32_t *>(L.prev) + wave * 1024;
+            static_assert(sizeof(L.prev) >= (kCT / 64) * 4096, "per-wave scratch of the parse");
+            uint32_t k = 0, s0 = 0;
+            for (uint32_t piece = 0; piece < L.ncut; piece++) {
+                const uint32_t c = L.cut[piece], e0 = c & 0x7FFFFFFFu;
+                if (piece % (kCT / 64) == wave && e0 > s0)
+                    optimal_parse_piece(L, in, mp, s0, e0, blkcost + k * kBlkCostStride, ws);
+                s0 = e0;
+                k += c >> 31;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            L.entry = 0;
+            L.block_start = 0;
+            L.block_ntok = 0;
+            L.m_len[0] = 0;
+            L.m_off[0] = 0;
+        }
+        __syncthreads();
+        n_eff = L.blk_end[0];
+    }
+    for (uint32_t b0 = 0; b0 < n;) {
         // ---- slide the LDS input window when the batch (plus the longest match) would
         //      run off its end; 32 KiB of history stay behind b0 ---------------------------
-        if (b0 + kCT + 258 + 8 > w0 + kInBuf - 16 && staged < n) {
+        if (!replay && b0 + kCT + 258 + 8 > w0 + kInBuf - 16 && staged < n) {
             constexpr uint32_t kUnits = (kInBuf - kInSlide) / 16, kPer = (kUnits + kCT - 1) / kCT;
             uint4 v[kPer];
 #pragma unroll
@@ -712,10 +874,11 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         DT_MARK(0);
         // LDS address of the input byte at chunk position q (q >= w0)
         auto inp = [&](uint32_t q) -> const uint8_t * { return &L.inbuf[q + phase - w0]; };
+        auto byte_at = [&](uint32_t q) -> uint32_t { return replay ? in[q] : *inp(q); };
         // ---- match: slot i+1 of the parse tables = position b0 + i ----------------
         const uint32_t p = b0 + tid;
         uint32_t best_len = 0, best_off = 0;
-        const bool can = p + 3 <= n;   // matchfinder.rs:765-767
+        const bool can = !replay && p + 3 <= n;   // matchfinder.rs:765-767
         // chains link positions by a hash of 4 bytes; a second table remembers the newest
         // position per 3-byte hash for the matches of length 3 the chains cannot see
         const bool can4 = p + 4 <= n;
@@ -751,7 +914,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             const uint32_t max_dist = p < 32768 ? p : 32768;   // matchfinder.rs:818
             const uint8_t *src = inp(p);
             const uint64_t src_a = load_le64(src + 4), src_b = load_le64(src + 12);
-            uint32_t dist = 0;
+            uint32_t dist = 0, npairs = 0;
+            uint32_t *mpp = mp + (size_t)p * kPairs;
             bool alive = true;
             for (uint32_t depth = 0; depth < lp.max_depth; depth++) {
                 dist += link;
@@ -770,6 +934,12 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 best_len = better ? l : best_len;
                 best_off = better ? dist : best_off;
                 alive = l < stop_len;                  // matchfinder.rs:825, :851
+                if (analysis && better) {
+                    // matches of increasing length, nearest first; the last slot keeps the longest
+                    const uint32_t slot = npairs < kPairs ? npairs : kPairs - 1;
+                    mpp[slot] = l | ((dist - 1) << 9);
+                    npairs = slot + 1;
+                }
             }
             if (best_len < 3 && older3 != 0) {
                 // length 3 only pays at short distances
@@ -777,8 +947,16 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 if (d - 1 < kMaxDist3 && d <= p && ((load_le32(inp(p - d)) ^ src4) & 0xFFFFFF) == 0) {
                     best_len = 3;
                     best_off = d;
+                    if (analysis) mpp[npairs++] = 3 | ((d - 1) << 9);
                 }
             }
+            if (analysis && npairs < kPairs) mpp[npairs] = 0;
+        } else if (analysis && p < n) {
+            mp[(size_t)p * kPairs] = 0;
+        } else if (replay && p < n_eff) {
+            const uint32_t w = mp[(size_t)p * kPairs], len = w & 511;
+            best_len = len >= 3 ? len : 0;
+            best_off = (w >> 9) + 1;
         }
         L.m_len[tid + 1] = (uint16_t)best_len;
         L.m_off[tid + 1] = (uint16_t)(best_off - (best_off ? 1 : 0));  // dist-1 fits 15 bits
@@ -788,8 +966,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         // ---- parse: slots [0, lim) are decided in this batch ----------------------
         // slot s <-> position b0 - 1 + s.  The last position of the batch waits for its
         // successor's match (lazy rule) unless the chunk ends here.
-        const bool tail = b0 + kCT >= n;
-        const uint32_t nslots = (tail ? n - b0 : kCT) + 1;    // slots that hold a position
+        const bool tail = b0 + kCT >= n_eff;
+        const uint32_t nslots = (tail ? n_eff - b0 : kCT) + 1;    // slots that hold a position
         const uint32_t lim = tail ? nslots : nslots - 1;      // slots decided now
         const uint32_t base_pos = b0 - 1;                     // position of slot 0 (b0 = 0: unused)
         const uint32_t entry = L.entry;
@@ -802,9 +980,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 uint32_t len = L.m_len[s], pos = base_pos + s;
                 if (len >= 3) {
                     uint32_t len1 = (s + 1 < nslots) ? L.m_len[s + 1] : 0;
-                    if (lp.lazy && len < lp.nice_len && len1 > len) {
+                    if (lp.lazy && !replay && len < lp.nice_len && len1 > len) {
                         // compress/mod.rs:1290-1336 (one lazy step): literal, then the longer match
-                        t0 = *inp(pos);
+                        t0 = byte_at(pos);
                         t1 = tok_match(len1, (uint32_t)L.m_off[s + 1] + 1);
                         ntoks = 2;
                         my_next = s + 1 + len1;
@@ -814,7 +992,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                         my_next = s + len;
                     }
                 } else {
-                    t0 = *inp(pos);
+                    t0 = byte_at(pos);
                     ntoks = 1;
                     my_next = s + 1;
                 }
@@ -830,7 +1008,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 x_t0 = tok_match(len, (uint32_t)L.m_off[s] + 1);
                 x_next = s + len;
             } else {
-                x_t0 = *inp(pos);
+                x_t0 = byte_at(pos);
                 x_next = s + 1;
             }
             x_ntoks = 1;
@@ -911,11 +1089,33 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         DT_MARK(4);
         // ---- close the block when it is large enough or the chunk ends -------------
         const uint32_t covered = L.entry;   // every byte below is inside an emitted token
-        if (tail || covered - L.block_start >= kBlockSoft || L.block_ntok + 2 * kCT + 2 > kTokCap) {
-            const uint32_t block_end = tail ? n : covered;
-            flush_block(L, in, block_end, tail && last_chunk, tok, out_words);
+        if (replay) {
+            if (tail) {
+                flush_block(L, in, n_eff, n_eff == n && last_chunk, tok, out_words);
+                b0 = n_eff;
+                blk++;
+                n_eff = blk < L.nblk ? L.blk_end[blk] : n;
+            } else {
+                b0 += kCT;
+            }
+        } else {
+            if (tail || covered - L.block_start >= kBlockSoft || L.block_ntok + 2 * kCT + 2 > kTokCap) {
+                const uint32_t block_end = tail ? n : covered;
+                if (analysis) record_block(L, block_end, blkcost);
+                else flush_block(L, in, block_end, tail && last_chunk, tok, out_words);
+            } else if (analysis) {
+                // the parse is cut into pieces where the first pass has a token boundary, so
+                // the cheapest path of a piece is never dearer than the first pass's tokens
+                if (tid == 0) {
+                    const uint32_t last = L.ncut ? (L.cut[L.ncut - 1] & 0x7FFFFFFFu) : 0;
+                    if (covered - last >= kSegment) L.cut[L.ncut++] = covered;
+                }
+                __syncthreads();
+            }
+            b0 += kCT;
         }
         DT_MARK(5);
+    }
     }
     if (RSX_DEV_TIMERS && tid == 0)
         for (int k = 0; k < 6; k++) atomicAdd(&g_deflate_t[k], dt[k]);
@@ -973,9 +1173,11 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
     uint8_t *__restrict__ scratch, uint64_t scratch_stride, uint32_t *__restrict__ tokbuf,
-    uint32_t *__restrict__ chunk_size)
+    uint32_t *__restrict__ chunk_size, uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf)
 {
     __shared__ ChunkLds L;
+    uint32_t *mp = pairbuf ? pairbuf + (size_t)blockIdx.x * kChunk * kPairs : nullptr;
+    uint8_t *blkcost = costbuf + (size_t)blockIdx.x * kMaxBlocks * kBlkCostStride;
     const uint32_t total_chunks = chunk_first[n];
     uint32_t *tok = tokbuf + (size_t)blockIdx.x * kTokCap;
     for (uint32_t ch = blockIdx.x; ch < total_chunks && ch < chunk_slots; ch += gridDim.x) {
@@ -991,7 +1193,7 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
         const bool last = cb + clen >= len;
         uint32_t *outw = reinterpret_cast<uint32_t *>(scratch + (size_t)ch * scratch_stride);
         uint32_t sz;
-        sz = compress_chunk(L, in + ib + cb, clen, last, lp, tok, outw);
+        sz = compress_chunk(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
         if (threadIdx.x == 0) chunk_size[ch] = sz;
         __syncthreads();
     }
@@ -1067,14 +1269,19 @@ uint64_t chunk_upper_bound(size_t n, uint64_t total_in) { return total_in / kChu
 
 }  // namespace
 
-size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item)
+// upper bound on the workgroups deflate_launch starts
+static uint32_t deflate_grid_bound(uint64_t chunks) { return (uint32_t)(chunks < 1024 ? chunks : 1024); }
+
+size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int level)
 {
     (void)max_item;
     const uint64_t chunks = chunk_upper_bound(n, total_in);
+    const size_t pairs = level >= 10 ? align_up((size_t)deflate_grid_bound(chunks) * kChunk * kPairs * 4, 256) : 0;
     const uint64_t stride = kChunk + kScratchPad;
     return align_up(chunks * stride, 256) + align_up((chunks + 1) * 4, 256) * 2 +
            align_up((n + 1) * 4, 256) + align_up((size_t)1024 * kTokCap * 4, 256) +
-           checksum_ws_bytes(n, total_in) + 4096;
+           checksum_ws_bytes(n, total_in) + pairs +
+           align_up((size_t)1024 * kMaxBlocks * kBlkCostStride, 256) + 4096;
 }
 
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
@@ -1100,7 +1307,16 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     uint32_t *chunk_first = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
     uint32_t *tokbuf = static_cast<uint32_t *>(ws_take(e, (size_t)grid * kTokCap * 4));
     uint32_t *sums = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
-    if (!scratch || !chunk_size || !chunk_first || !tokbuf || !sums) {
+    uint8_t *costbuf = static_cast<uint8_t *>(ws_take(e, (size_t)grid * kMaxBlocks * kBlkCostStride));
+    uint32_t *pairbuf = nullptr;
+    if (level >= 10) {
+        pairbuf = static_cast<uint32_t *>(ws_take(e, (size_t)grid * kChunk * kPairs * 4));
+        if (!pairbuf) {
+            e->err = "workspace exhausted";
+            return RSX_E_NOMEM;
+        }
+    }
+    if (!scratch || !chunk_size || !chunk_first || !tokbuf || !sums || !costbuf) {
         e->err = "workspace exhausted";
         return RSX_E_NOMEM;
     }
@@ -1109,7 +1325,7 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     (void)hipEventRecord(e->ev_begin, e->stream);
     deflate_chunks_kernel<<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
                                                        (uint32_t)chunks, lp, scratch, stride, tokbuf,
-                                                       chunk_size);
+                                                       chunk_size, pairbuf, costbuf);
     (void)hipEventRecord(e->ev_end, e->stream);
     e->timed = true;
     RSX_HIP(e, hipGetLastError());

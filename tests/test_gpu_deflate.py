@@ -56,7 +56,7 @@ def test_reference_batch_tests(rsx, kat):
 
 
 @pytest.mark.parametrize("fmt", [0, 1, 2])
-@pytest.mark.parametrize("level", [0, 1, 4, 6, 9, 12])
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9, 10, 12])
 def test_roundtrip_formats_levels(eng, fmt, level):
     datas = [corpus.text(300000, 1), corpus.mixed(400000, 2), corpus.json_like(100000, 3), b"",
              b"a", b"abc", b"ab" * 3000, bytes(70000), corpus.random_bytes(5000, 4),
@@ -102,6 +102,23 @@ def test_level_ordering_and_ratio_vs_oracle(eng):
     for d, c in zip(t, comp):
         ref = o.compress(d, 6)
         assert len(c) <= 1.06 * len(ref), (len(c), len(ref))
+
+
+def test_cost_based_levels(eng):
+    # levels 10-12 (src/compress/mod.rs:1586-1773): valid streams in every format, no larger
+    # than the lazy parse with the deepest search, and smaller than the reference's level 9
+    # (the oracle has no restatement of the reference's levels 10-12 to compare against)
+    datas = [corpus.json_like(1 << 20, 21), corpus.text(700000, 22), corpus.mixed(300000, 23),
+             corpus.text(8191, 24), corpus.text(8193, 25), b"abcabcabc" * 5000, corpus.random_bytes(70000, 26)]
+    l9, _ = eng.batch_compress(datas, 0, 9)
+    for level in (10, 11, 12):
+        comp = roundtrip(eng, datas, 0, level)
+        if level == 12:
+            for d, c, c9 in zip(datas[:3], comp, l9):
+                assert len(c) <= len(c9), (len(c), len(c9))
+                assert len(c) < len(o.compress(d, 9))
+    roundtrip(eng, datas[:3], 1, 12)
+    roundtrip(eng, datas[:3], 2, 10)
 
 
 def test_api_surface(rsx):
