@@ -1,0 +1,83 @@
+"""The benchmark configurations' shapes through the C ABI, at sizes a test can afford,
+checked by properties that do not need a second implementation at full size: round
+trips, the engine's own trailer verification, determinism, and checksums of outputs
+against checksums of inputs."""
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+import oracle_lib as o
+import rsx_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rsx():
+    return rsx_pkg.load()
+
+
+@pytest.fixture(scope="module")
+def eng(rsx):
+    return rsx.default_engine()
+
+
+def test_random_64k_buffers_roundtrip(eng):
+    # 256 x 64 KiB random bytes, raw DEFLATE level 6, compress then decompress: the
+    # reference fails these (no stored fallback); the engine stores them inside the bound
+    datas = [corpus.random_bytes(65536, 100 + i) for i in range(256)]
+    comp, st = eng.batch_compress(datas, 0, 6)
+    assert (np.asarray(st) == 0).all()
+    assert all(len(c) <= o.compress_bound(0, 65536) for c in comp)
+    back, st = eng.batch_decompress(comp, [65536] * 256, 0)
+    assert (np.asarray(st) == 0).all() and back == datas
+    for c, d in zip(comp[:8], datas[:8]):
+        assert o.decompress(c, 65536, 0) == (o.SUCCESS, len(c), d)
+
+
+def test_many_small_gzip_streams(eng):
+    # 8192 x 64 KiB gzip level-6 text streams (single segment each), 32 distinct sources;
+    # every trailer (CRC-32 + ISIZE) is verified by the engine, outputs compared bytewise
+    distinct = [corpus.text(65536, 200 + i) for i in range(32)]
+    streams = [o.compress(d, 6, 2) for d in distinct]
+    n = 8192
+    got, st = eng.batch_decompress([streams[i % 32] for i in range(n)], [65536] * n, 2)
+    assert (np.asarray(st) == 0).all()
+    for i in range(n):
+        assert got[i] == distinct[i % 32], i
+
+
+def test_large_json_buffers_top_level(eng):
+    # 4 MiB JSON buffers at level 12 (16 chunks each, cost-based parse), raw DEFLATE
+    datas = [corpus.json_like(4 << 20, 300 + i) for i in range(4)]
+    comp, st = eng.batch_compress(datas, 0, 12)
+    assert (np.asarray(st) == 0).all()
+    comp6, _ = eng.batch_compress(datas, 0, 6)
+    for d, c, c6 in zip(datas, comp, comp6):
+        assert len(c) < len(c6)
+        assert zlib.decompress(c, -15) == d
+    back, st = eng.batch_decompress(comp, [len(d) for d in datas], 0)
+    assert (np.asarray(st) == 0).all() and back == datas
+    assert o.decompress(comp[0], len(datas[0]), 0) == (o.SUCCESS, len(comp[0]), datas[0])
+
+
+def test_determinism_and_checksum_of_outputs(eng, rsx):
+    datas = [corpus.mixed(1 << 20, 400 + i) for i in range(16)]
+    a, _ = eng.batch_compress(datas, 1, 6)
+    b, _ = eng.batch_compress(datas, 1, 6)
+    assert a == b   # same input, same bytes, whatever the scheduling
+    back, st = eng.batch_decompress(a, [1 << 20] * 16, 1)
+    assert (np.asarray(st) == 0).all()
+    crc_in = eng.batch_checksum(datas, rsx.CHECKSUM_CRC32)
+    crc_out = eng.batch_checksum(back, rsx.CHECKSUM_CRC32)
+    assert list(crc_in) == list(crc_out) == [zlib.crc32(d) for d in datas]
+    # a checksum of the checksums, chained through the one-shot entry point
+    chain = 0
+    for v in crc_out:
+        chain = rsx.crc32(chain, int(v).to_bytes(4, "little"))
+    want = 0
+    for d in datas:
+        want = zlib.crc32(zlib.crc32(d).to_bytes(4, "little"), want)
+    assert chain == want
