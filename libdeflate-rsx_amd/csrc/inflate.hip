@@ -629,7 +629,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     // that changed are compacted into a work list and re-decoded by the first lanes
     // of the workgroup, so late passes (few stragglers) occupy one wave, not all.
     uint32_t start = lo;          // lane 0's guess is exact
-    unsigned long long tq = RSX_DEV_TIMERS ? clock64() : 0;
+    unsigned long long tq = RSX_DEV_TIMERS == 1 ? clock64() : 0;
     Scan sc;
     if (start >= bound) {
         sc = Scan{start, 0, 0};   // nothing starts here (window exhausted)
@@ -640,7 +640,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     L.spec.sub_bytes[tid] = (uint16_t)sc.bytes;
     L.spec.sub_nm[tid] = (uint16_t)sc.nm;
     __syncthreads();
-    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tq; tq = t; }
+    if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tq; tq = t; }
     // the true prefix grows by at least one sub-sequence per pass, so kT passes suffice
     for (int pass = 0; pass <= kT; pass++) {
         __syncthreads();
@@ -688,7 +688,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     sc.bytes = L.spec.sub_bytes[tid];
     sc.nm = L.spec.sub_nm[tid];
     __syncthreads();
-    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tq; tq = t; }
+    if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tq; tq = t; }
     // every start now follows from lane 0's: the first lane that ended the block
     // (or the input) is real, and nothing behind it belongs to this block
     if (tid == 0) {
@@ -713,7 +713,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     __syncthreads();
     const bool last = commit && (tid == kT - 1 || !(L.lane_exit[tid + 1] & 0x10000000u));
 
-    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tq; tq = t; }
+    if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tq; tq = t; }
     // ---- emit -------------------------------------------------------------------------
     if (commit) {
         uint32_t b = start;
@@ -755,7 +755,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
     }
     __syncthreads();
-    if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tq; tq = t; }
+    if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tq; tq = t; }
     if (last) {
         const uint32_t ee = L.emit_error;
         L.bitpos = (uint64_t)(win_bit0 + (int64_t)(sc.exit & kExitPosMask));
@@ -794,6 +794,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub) {
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         const uint32_t n = sub_end - sub_start;
+        unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
         for (uint32_t i = tid; i < n; i += kT) ptr[i] = (uint16_t)kSelf;
         __syncthreads();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
@@ -810,6 +811,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (uint32_t pos = from; pos < to; pos++) ptr[pos - sub_start] = (uint16_t)(pos + bias);
             if (dst + len <= sub_end) consumed++;
         }
+        if (RSX_DEV_TIMERS == 2) { __syncthreads(); if (tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; } }
         // advance mcur by the number of matches that end inside this step
         {
             uint32_t x = consumed;
@@ -818,33 +820,61 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         }
         __syncthreads();
         for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
+        if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tc; tc = t; }
         // pointer jumping: a pointer into this step that lands on a non-literal byte
         // takes over that byte's pointer
+        // (all reads of a round are issued before the first dependent one is needed)
+        constexpr int kPer = kCopySub / kT;
         for (int round = 0; round < 16; round++) {
             bool changed = false;
-            for (uint32_t i = tid; i < n; i += kT) {
-                const uint32_t v = ptr[i];
-                if (v != kSelf && v >= kBack) {
-                    const uint32_t v2 = ptr[v - kBack];
-                    if (v2 != kSelf) {
-                        ptr[i] = (uint16_t)v2;
-                        changed = true;
-                    }
+            uint32_t v[kPer], v2[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const uint32_t i = tid + k * kT;
+                v[k] = i < n ? ptr[i] : kSelf;
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const bool hop = v[k] != kSelf && v[k] >= kBack;
+                v2[k] = hop ? ptr[v[k] - kBack] : kSelf;
+            }
+            __syncthreads();   // every read of this round precedes its writes
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                if (v2[k] != kSelf) {
+                    ptr[tid + k * kT] = (uint16_t)v2[k];
+                    // a pointer that now leaves the step is final; only one that still
+                    // points into the step can need another round
+                    changed = changed || v2[k] >= kBack;
                 }
             }
             if (!__syncthreads_or(changed)) break;
         }
+        if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
         // bytes that have left the ring (read back from the output)
-        for (uint32_t i = tid; i < n; i += kT) {
-            const uint32_t v = ptr[i];
-            if (v != kSelf) {
-                const int64_t sp = (int64_t)sub_start - kBack + v;
-                const uint8_t byte = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask] : c.out[sp];
-                L.ring[(sub_start + i + c.shift) & kRingMask] = byte;
+        {
+            uint32_t v[kPer];
+            uint8_t byte[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const uint32_t i = tid + k * kT;
+                v[k] = i < n ? ptr[i] : kSelf;
             }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                byte[k] = 0;
+                if (v[k] != kSelf) {
+                    const int64_t sp = (int64_t)sub_start - kBack + v[k];
+                    byte[k] = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask] : c.out[sp];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if (v[k] != kSelf) L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = byte[k];
         }
         __syncthreads();
+        if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tc; tc = t; }
     }
     __syncthreads();
 }
