@@ -283,8 +283,23 @@ def main():
     for i in range(distinct):
         ok = ok and host_out[i * buf:(i + 1) * buf].tobytes() == texts[i]
     if not ok:
-        raise SystemExit("bench.py: GPU output does not match the input texts (status %s)"
-                         % np.unique(st))
+        bad = np.nonzero((st != 0) | (sz != buf))[0]
+        for i in bad[:6]:   # where the output of a failed stream first departs from its text
+            got = d_out[int(i) * buf:(int(i) + 1) * buf].cpu().numpy()
+            want = np.frombuffer(texts[int(i) % distinct], dtype=np.uint8)
+            diff = np.nonzero(got != want)[0]
+            p0 = int(diff[0]) if len(diff) else -1
+            shift = [k for k in range(1, 64) if p0 >= 0 and p0 + k + 64 <= buf
+                     and (got[p0 + k:p0 + k + 64] == want[p0:p0 + 64]).all()]
+            if p0 >= 0:
+                print("[bench]   want %r" % want[max(0, p0 - 24):p0 + 72].tobytes(), file=sys.stderr)
+                print("[bench]   got  %r" % got[max(0, p0 - 24):p0 + 72].tobytes(), file=sys.stderr)
+            print("[bench] stream %d status %d first mismatch at %d (%d differing bytes), "
+                  "output continues the text after an insertion of %s bytes"
+                  % (i, st[i], p0, len(diff), shift[:1] or "?"), file=sys.stderr)
+        raise SystemExit("bench.py: GPU output does not match the input texts (status values %s, %d bad "
+                         "streams, first %s, their status %s sizes %s)"
+                         % (np.unique(st), len(bad), bad[:8], st[bad[:8]], sz[bad[:8]]))
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

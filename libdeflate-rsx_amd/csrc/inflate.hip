@@ -467,13 +467,14 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
 // wave that holds literals, match halves and subtable hops at once does not diverge.
 //
 // Bit buffer: 64 bits per lane, refilled 32 bits at a time from the staged window;
-// the next window dword is always already loaded, so a refill adds no LDS round
+// the next two window dwords are always already loaded, so a refill adds no LDS round
 // trip to the step-to-step dependency chain.
 struct Decoder {
     uint64_t bb;     // unread bits, LSB first
     uint32_t bc;     // valid bits in bb
     uint32_t wnext;  // index of the prefetched window dword
     uint32_t nextw;  // win[wnext]
+    uint32_t next2;  // win[wnext + 1], so that a refill never waits for its load
     uint32_t b;      // window bit position of the next unread bit
     uint32_t tok;    // window bit position where the current token starts
     uint32_t pend;   // match length waiting for its distance (0 = litlen phase)
@@ -487,6 +488,7 @@ struct Decoder {
         bc = 64 - (at & 31);
         wnext = w + 2;
         nextw = L.win[wnext];
+        next2 = L.win[wnext + 1];
         b = tok = at;
         pend = 0;
         tbase = 0;
@@ -508,7 +510,8 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d, uint32_t 
     d.bb |= low ? (uint64_t)d.nextw << d.bc : 0ull;
     d.bc += low ? 32u : 0u;
     d.wnext += low ? 1u : 0u;
-    if (low) d.nextw = L.win[d.wnext];
+    d.nextw = low ? d.next2 : d.nextw;
+    d.next2 = L.win[d.wnext + 1];   // unconditional (no branch); first needed a refill later
 
     const uint32_t bits = (uint32_t)d.bb;
     const uint32_t e = L.litlen[d.tbase + (bits & d.tmask)];
@@ -557,22 +560,21 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
     Scan r{start, 0, 0};
     Decoder d;
     d.init(L, start, litlen_mask);
-    // a token is in flight while tok != b (length read, subtable hop)
-    while (d.tok != d.b || d.b < bound) {
+    // window bit positions are far below 2^31: compare in 32 bits
+    const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
+    // a token is in flight while tok != b (length read, subtable hop).  One exit test per
+    // step; everything else is selects.
+    bool running = d.b < bound;
+    while (running) {
         const uint32_t t0 = d.tok;
         const StepOut o = decoder_step(L, d, litlen_mask);
-        if ((int64_t)d.b > end_b) {
-            r.exit = t0 | kExitStop;
-            return r;
-        }
-        r.bytes += o.kind == 2 ? o.len : (o.kind == 1 ? 1u : 0u);
-        r.nm += o.kind == 2 ? 1u : 0u;
-        if (o.kind == 3) {
-            r.exit = d.b | kExitEob;
-            return r;
-        }
+        const bool over = d.b > end32;            // ran past the body: stop at the token start
+        const bool eob = !over && o.kind == 3;
+        r.bytes += over ? 0u : o.kind == 2 ? o.len : (o.kind == 1 ? 1u : 0u);
+        r.nm += (!over && o.kind == 2) ? 1u : 0u;
+        r.exit = over ? (t0 | kExitStop) : eob ? (d.b | kExitEob) : d.b;
+        running = !over && !eob && (d.tok != d.b || d.b < bound);
     }
-    r.exit = d.b;
     return r;
 }
 
@@ -823,29 +825,17 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tc; tc = t; }
         // pointer jumping: a pointer into this step that lands on a non-literal byte
         // takes over that byte's pointer
-        // (all reads of a round are issued before the first dependent one is needed)
         constexpr int kPer = kCopySub / kT;
         for (int round = 0; round < 16; round++) {
             bool changed = false;
-            uint32_t v[kPer], v2[kPer];
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const uint32_t i = tid + k * kT;
-                v[k] = i < n ? ptr[i] : kSelf;
-            }
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const bool hop = v[k] != kSelf && v[k] >= kBack;
-                v2[k] = hop ? ptr[v[k] - kBack] : kSelf;
-            }
-            __syncthreads();   // every read of this round precedes its writes
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                if (v2[k] != kSelf) {
-                    ptr[tid + k * kT] = (uint16_t)v2[k];
-                    // a pointer that now leaves the step is final; only one that still
-                    // points into the step can need another round
-                    changed = changed || v2[k] >= kBack;
+            for (uint32_t i = tid; i < n; i += kT) {
+                const uint32_t v = ptr[i];
+                if (v != kSelf && v >= kBack) {
+                    const uint32_t v2 = ptr[v - kBack];
+                    if (v2 != kSelf) {
+                        ptr[i] = (uint16_t)v2;
+                        changed = true;
+                    }
                 }
             }
             if (!__syncthreads_or(changed)) break;
