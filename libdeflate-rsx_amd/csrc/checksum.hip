@@ -108,18 +108,18 @@ __device__ inline SegInfo locate(const uint8_t *in, const uint64_t *starts, cons
 __device__ inline uint32_t wg_reduce_xor(uint32_t v, uint32_t *lds)
 {
     for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
-    __syncthreads();
+    WG_SYNC();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-    __syncthreads();
+    WG_SYNC();
     return lds[0] ^ lds[1] ^ lds[2] ^ lds[3];
 }
 
 __device__ inline uint64_t wg_reduce_add(uint64_t v, uint64_t *lds)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
+    WG_SYNC();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-    __syncthreads();
+    WG_SYNC();
     return lds[0] + lds[1] + lds[2] + lds[3];
 }
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
     }
     uint32_t item;
     SegInfo s = locate(in, starts, lens, n, seg_start, segs_per_item, &item);
-    __syncthreads();
+    WG_SYNC();
     if (!s.valid) return;  // slot past the end of a short item: never read by the fold
     const uint64_t seg_begin = (uint64_t)s.seg * kSeg;
     const uint32_t L = (uint32_t)((s.len - seg_begin) < kSeg ? (s.len - seg_begin) : kSeg);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint64_t *__restri
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    WG_SYNC();
     for (uint32_t base = 0; base < n; base += 1024) {
         uint32_t i = base + threadIdx.x;
         uint32_t c = 0;
@@ -269,13 +269,13 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint64_t *__restri
             if ((int)(threadIdx.x & 63) >= o) x += y;
         }
         if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-        __syncthreads();
+        WG_SYNC();
         uint32_t before = carry;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
         if (i < n) seg_start[i] = before + x - c;
-        __syncthreads();
+        WG_SYNC();
         if (threadIdx.x == 1023) carry = before + x;
-        __syncthreads();
+        WG_SYNC();
     }
     if (threadIdx.x == 0) seg_start[n] = carry;
 }

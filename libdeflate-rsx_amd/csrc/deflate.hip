@@ -251,7 +251,7 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
         if (sym < 16) len_counts[sym] = sym == 1 ? 2 : 0;
         if (sym == 0) *flag = 0;
     }
-    __syncthreads();
+    WG_SYNC();
     if (on && sym == 0) {
         if (used < 2) {
             // huffman_comp.rs:133-145: two 1-bit codes so the code is complete
@@ -265,20 +265,20 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
             huff_build_tree((lds_u32 *)a, used);
         }
     }
-    __syncthreads();
+    WG_SYNC();
     // depth of the internal nodes by pointer jumping: word = depth << 16 | ancestor
     const bool tree = on && used >= 2;
     const uint32_t root = used - 2;
     const bool node = tree && sym <= root;
     if (node) pj[sym] = sym == root ? root : ((1u << 16) | (a[sym] >> kSymBits));
-    __syncthreads();
+    WG_SYNC();
     uint32_t cur = 0;
     for (uint32_t span = 1; span < largest_alphabet; span <<= 1) {   // same trip count on all lanes
         if (node) {
             const uint32_t w = pj[cur + sym], up = pj[cur + (w & 0xFFFF)];
             pj[(cur ^ num_syms) + sym] = ((w & 0xFFFF0000u) + (up & 0xFFFF0000u)) | (up & 0xFFFF);
         }
-        __syncthreads();
+        WG_SYNC();
         cur ^= num_syms;
     }
     // without an over-long code, len_counts is the histogram the walk would produce
@@ -291,9 +291,9 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
             atomicAdd(&len_counts[depth + 1], 2u);
         }
     }
-    __syncthreads();
+    WG_SYNC();
     if (tree && sym == 0 && *flag) huff_limit_lengths((lds_u32 *)a, used, max_len, (lds_u32 *)len_counts);
-    __syncthreads();
+    WG_SYNC();
     // gen_codewords (huffman_comp.rs:95-123): sorted index i takes the longest lengths first
     if (tree && sym < used) {
         uint32_t c = 0, len = max_len;
@@ -303,7 +303,7 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
         }
         lens[a[sym] & kSymMask] = (uint8_t)len;
     }
-    __syncthreads();
+    WG_SYNC();
     if (tree) {
         const uint32_t len = lens[sym];
         if (len) {
@@ -313,7 +313,7 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
             codes[sym] = reverse_bits(next, len);
         }
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // bits of one token under the open block's codes
@@ -341,9 +341,9 @@ __device__ inline uint32_t wg_exclusive_scan(ChunkLds &L, uint32_t v, uint32_t *
         uint32_t y = __shfl_up(x, o);
         if (lane >= o) x += y;
     }
-    __syncthreads();
+    WG_SYNC();
     if (lane == 63) L.scan_tmp[w] = x;
-    __syncthreads();
+    WG_SYNC();
     uint32_t before = 0, all = 0;
     for (int k = 0; k < kCT / 64; k++) {
         uint32_t s = L.scan_tmp[k];
@@ -408,7 +408,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
         L.body_bits = 0;
     }
     if (tid < 19) L.pre_freq[tid] = 0;
-    __syncthreads();
+    WG_SYNC();
     unsigned long long fq = RSX_DEV_TIMERS ? clock64() : 0;
     const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
     const uint32_t osym = tid - 320;
@@ -434,7 +434,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
         for (int o = 32; o; o >>= 1) bb += __shfl_xor(bb, o);
         if ((tid & 63) == 0 && bb) atomicAdd(&L.body_bits, bb);
     }
-    __syncthreads();
+    WG_SYNC();
     const uint32_t nl = L.nl, no = L.no, total = nl + no;
     auto len_at = [&](uint32_t i) -> uint32_t { return i < nl ? L.litlen_len[i] : L.off_len[i - nl]; };
     // ---- run-length items: the first lane of every run of equal lengths writes them ----
@@ -448,7 +448,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
         const unsigned long long bal = __ballot(start);
         if ((tid & 63) == 0 && tid < 320) L.run_mask[tid >> 6] = bal;
     }
-    __syncthreads();
+    WG_SYNC();
     uint32_t run = 0, cnt = 0;
     if (start) {
         uint32_t nxt = total;
@@ -475,7 +475,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
             items[ioff++] = (uint16_t)((sym << 8) | extra);
             atomicAdd(&L.pre_freq[sym], 1u);
         });
-    __syncthreads();
+    WG_SYNC();
     // ---- precode -----------------------------------------------------------------------
     huff_collective(tid < 19, tid, 19u, 7u, L.pre_freq, L.pre_len, L.pre_code, L.huff_scratch,
                     L.len_counts[0], pj, &L.huff_flag[0], 19u);
@@ -493,7 +493,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
     const uint64_t pos = L.out_bits;
     const uint64_t stored_bits = (((pos + 3 + 7) & ~7ull) - pos) + 32 + 8ull * block_bytes;
     const bool stored = block_bytes <= 65535 && stored_bits <= hdr_bits + body_bits;
-    __syncthreads();   // everyone has read out_bits
+    WG_SYNC();   // everyone has read out_bits
     if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[7], t_ - fq); fq = t_; }
     if (stored) {
         // stored block (src/compress/mod.rs:1408-1448): header bits, align, LEN, NLEN, bytes
@@ -571,7 +571,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
             L.out_bits = e + L.litlen_len[256];
         }
     }
-    __syncthreads();
+    WG_SYNC();
     // reset the block state
     for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
     if (tid < 32) L.off_freq[tid] = 0;
@@ -579,7 +579,7 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
         L.block_ntok = 0;
         L.block_start = block_end;
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 __device__ inline uint32_t load_le32(const uint8_t *p)
@@ -626,7 +626,7 @@ __device__ void record_block(ChunkLds &L, uint32_t block_end, uint8_t *blkcost)
     const uint32_t tid = threadIdx.x;
     uint32_t *pj = reinterpret_cast<uint32_t *>(L.jump);
     if (tid == 0) L.litlen_freq[256] = 1;
-    __syncthreads();
+    WG_SYNC();
     const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
     const uint32_t osym = tid - 320;
     huff_collective(is_ll || is_off, is_ll ? tid : osym, is_ll ? 288u : 32u, is_ll ? 14u : 15u,
@@ -638,7 +638,7 @@ __device__ void record_block(ChunkLds &L, uint32_t block_end, uint8_t *blkcost)
     uint8_t *bc = blkcost + k * kBlkCostStride;
     if (is_ll) bc[tid] = L.litlen_len[tid];
     if (is_off) bc[288 + osym] = L.off_len[osym];
-    __syncthreads();
+    WG_SYNC();
     for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
     if (tid < 32) L.off_freq[tid] = 0;
     if (tid == 0) {
@@ -648,7 +648,7 @@ __device__ void record_block(ChunkLds &L, uint32_t block_end, uint8_t *blkcost)
         L.block_ntok = 0;
         L.block_start = block_end;
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // One wave: cheapest path over positions [s, e) of a block whose code lengths are bc.
@@ -768,13 +768,13 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.ncut = 0;
         }
     }
-    __syncthreads();
+    WG_SYNC();
 
     // LDS input window
     const uint32_t phase = (uint32_t)((uintptr_t)in & 15);
     uint32_t w0 = 0, staged = kInBuf - 16 < n ? kInBuf - 16 : n;
     if (lp.max_depth != 0) stage_input(L, in, n, 0, phase, 0, staged);
-    __syncthreads();
+    WG_SYNC();
 
     if (n == 0) {
         // an empty input is an empty final fixed-Huffman block: BFINAL=1, BTYPE=01, end-of-block (7 zero bits)
@@ -782,7 +782,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             if (last_chunk) or_bits(out_words, 0, 3, 3);
             L.out_bits = last_chunk ? 10 : 0;
         }
-        __syncthreads();
+        WG_SYNC();
     }
 
     if (lp.max_depth == 0) {
@@ -797,12 +797,12 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 or_bits(out_words, q + 16, (~blen) & 0xFFFF, 16);
                 L.out_bits = q + 32;
             }
-            __syncthreads();
+            WG_SYNC();
             uint8_t *ob = reinterpret_cast<uint8_t *>(out_words) + (L.out_bits >> 3);
             for (uint32_t k = tid; k < blen; k += kCT) ob[k] = in[pos + k];
-            __syncthreads();
+            WG_SYNC();
             if (tid == 0) L.out_bits += 8ull * blen;
-            __syncthreads();
+            WG_SYNC();
         }
         n = 0;  // nothing left for the matcher
     }
@@ -819,7 +819,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
     uint32_t n_eff = n;   // replay: end of the block being replayed
     if (replay) {
         __threadfence();
-        __syncthreads();
+        WG_SYNC();
         // pieces of all blocks, dealt round-robin to the waves; the hash tables are idle now
         {
             const uint32_t wave = tid >> 6;
@@ -835,7 +835,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             }
         }
         __threadfence();
-        __syncthreads();
+        WG_SYNC();
         if (tid == 0) {
             L.entry = 0;
             L.block_start = 0;
@@ -843,7 +843,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.m_len[0] = 0;
             L.m_off[0] = 0;
         }
-        __syncthreads();
+        WG_SYNC();
         n_eff = L.blk_end[0];
     }
     for (uint32_t b0 = 0; b0 < n;) {
@@ -857,19 +857,19 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 uint32_t u = tid + k * kCT;
                 if (u < kUnits) v[k] = reinterpret_cast<const uint4 *>(L.inbuf)[u + kInSlide / 16];
             }
-            __syncthreads();
+            WG_SYNC();
 #pragma unroll
             for (uint32_t k = 0; k < kPer; k++) {
                 uint32_t u = tid + k * kCT;
                 if (u < kUnits) reinterpret_cast<uint4 *>(L.inbuf)[u] = v[k];
             }
             w0 += kInSlide;
-            __syncthreads();
+            WG_SYNC();
             const uint32_t upto = w0 + kInBuf - 16 < n ? w0 + kInBuf - 16 : n;
             // restage from the 16-byte unit that holds `staged` (its head is already there)
             stage_input(L, in, n, w0, phase, staged, upto);
             staged = upto;
-            __syncthreads();
+            WG_SYNC();
         }
         DT_MARK(0);
         // LDS address of the input byte at chunk position q (q >= w0)
@@ -901,7 +901,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 L.prev[p & (kWindow - 1)] = (uint16_t)link;
                 older3 = atomicExch(&L.head3[h3], p + 1);
             }
-            __syncthreads();
+            WG_SYNC();
         }
         DT_MARK(1);
         if (can && lp.max_depth) {
@@ -960,7 +960,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         }
         L.m_len[tid + 1] = (uint16_t)best_len;
         L.m_off[tid + 1] = (uint16_t)(best_off - (best_off ? 1 : 0));  // dist-1 fits 15 bits
-        __syncthreads();
+        WG_SYNC();
         DT_MARK(2);
 
         // ---- parse: slots [0, lim) are decided in this batch ----------------------
@@ -1023,9 +1023,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.mark[kCT] = 0;
             L.mark[kEnd] = 0;
         }
-        __syncthreads();
+        WG_SYNC();
         if (tid == 0 && entry_slot < lim) L.mark[entry_slot] = 1;
-        __syncthreads();
+        WG_SYNC();
         int cur = 0;
         for (uint32_t span = 1; span < kCT + 2; span <<= 1) {
             // marked slots mark their 2^k-th successor; then square the jump table
@@ -1033,7 +1033,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             uint32_t j = L.jump[cur][s];
             uint32_t jx = (tid == kCT - 1) ? L.jump[cur][kCT] : kEnd;
             bool mk = L.mark[s] != 0, mkx = (tid == kCT - 1) && L.mark[kCT] != 0;
-            __syncthreads();
+            WG_SYNC();
             if (mk && j < lim) L.mark[j] = 1;
             if (mkx && jx < lim) L.mark[jx] = 1;
             L.jump[cur ^ 1][s] = L.jump[cur][j];
@@ -1041,7 +1041,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 L.jump[cur ^ 1][kCT] = L.jump[cur][jx];
                 L.jump[cur ^ 1][kEnd] = (uint16_t)kEnd;
             }
-            __syncthreads();
+            WG_SYNC();
             cur ^= 1;
         }
         DT_MARK(3);
@@ -1077,7 +1077,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             }
             L.next_entry = base_pos + x_next;
         }
-        __syncthreads();
+        WG_SYNC();
         if (tid == 0) {
             if (total) L.entry = L.next_entry;
             L.block_ntok = tbase + total;
@@ -1085,7 +1085,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.m_len[0] = L.m_len[kCT];
             L.m_off[0] = L.m_off[kCT];
         }
-        __syncthreads();
+        WG_SYNC();
         DT_MARK(4);
         // ---- close the block when it is large enough or the chunk ends -------------
         const uint32_t covered = L.entry;   // every byte below is inside an emitted token
@@ -1110,7 +1110,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                     const uint32_t last = L.ncut ? (L.cut[L.ncut - 1] & 0x7FFFFFFFu) : 0;
                     if (covered - last >= kSegment) L.cut[L.ncut++] = covered;
                 }
-                __syncthreads();
+                WG_SYNC();
             }
             b0 += kCT;
         }
@@ -1132,7 +1132,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         }
         L.out_bits = p;
     }
-    __syncthreads();
+    WG_SYNC();
     return (uint32_t)(L.out_bits >> 3);
 }
 
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__rest
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    WG_SYNC();
     for (uint32_t base = 0; base < n; base += 1024) {
         uint32_t i = base + threadIdx.x;
         uint32_t c = i < n ? chunks_of(in_off[i + 1] - in_off[i]) : 0;
@@ -1157,13 +1157,13 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__rest
             if ((int)(threadIdx.x & 63) >= o) x += y;
         }
         if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-        __syncthreads();
+        WG_SYNC();
         uint32_t before = carry;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
         if (i < n) chunk_first[i] = before + x - c;
-        __syncthreads();
+        WG_SYNC();
         if (threadIdx.x == 1023) carry = before + x;
-        __syncthreads();
+        WG_SYNC();
     }
     if (threadIdx.x == 0) chunk_first[n] = carry;
 }
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
         uint32_t sz;
         sz = compress_chunk(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
         if (threadIdx.x == 0) chunk_size[ch] = sz;
-        __syncthreads();
+        WG_SYNC();
     }
 }
 

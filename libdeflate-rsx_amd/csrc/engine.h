@@ -48,6 +48,13 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- kernel launchers (each defined next to its kernels) ---------------------
 
+// Workgroup barrier.  The LDS writes of a wave must have landed before it signals the
+// barrier.  __syncthreads() alone leaves that to the compiler's wait-count insertion, which
+// (ROCm 7.2) drops the wait in front of a barrier at the head of a loop whose body ends in
+// LDS writes; other waves then read stale values when the LDS queue is deep.  The wait is
+// therefore written out.
+#define WG_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+
 // checksum.hip
 int checksum_tables_create(rsx_engine *e);
 size_t checksum_ws_bytes(size_t n, uint64_t total_in);

@@ -38,6 +38,9 @@
 #ifndef RSX_DEV_TIMERS
 #define RSX_DEV_TIMERS 0
 #endif
+#ifndef RSX_DBG
+#define RSX_DBG 0   // development checks
+#endif
 
 namespace {
 
@@ -121,7 +124,6 @@ struct HeaderScratch {
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
     uint8_t precode_lens[20];
-    uint32_t len_counts[16], offsets[16];   // working arrays of the table build
 };
 struct SpecScratch {
     uint32_t sub_start[kT];       // start handed to a sub-sequence that is re-decoded
@@ -143,6 +145,7 @@ struct __align__(16) StreamLds {
         MatchQueue mq;
     };
     uint32_t lane_exit[kT];
+    uint32_t len_counts[16], offsets[16];   // working arrays of the table build
     uint32_t scan_carry[2 * (kT / 64)];
     uint32_t emit_error;          // min over lanes of lane << 8 | DecompressResult
     uint32_t stat_spec, stat_copy; // pass counters (STATS builds)
@@ -324,11 +327,14 @@ __device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *w
 // and build the three tables.  Runs on one thread; reads bits through the
 // staged window, which the caller guarantees covers the whole header
 // (a header is at most 14 + 19*3 + 320*(7+7) bits < 600 bytes).
-__device__ __noinline__ int read_dynamic_header(LdsStream &L, uint32_t *bp, int64_t win_bit0, uint64_t end_bit)
+struct HeaderResult {
+    int code;      // DecompressResult
+    uint32_t b;    // window bit position behind the header (by value: no pointer into the caller's stack)
+};
+__device__ __noinline__ HeaderResult read_dynamic_header(LdsStream &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
 {
-    uint32_t b = *bp;
     auto avail = [&](uint32_t need) { return (uint64_t)(win_bit0 + b + need) <= end_bit; };
-    if (!avail(14)) return RSX_SHORT_INPUT;
+    if (!avail(14)) return HeaderResult{RSX_SHORT_INPUT, b};
     uint32_t bits = fetch_bits(L.win, b);
     uint32_t num_litlen = 257 + (bits & 0x1F);
     uint32_t num_offset = 1 + ((bits >> 5) & 0x1F);
@@ -336,21 +342,21 @@ __device__ __noinline__ int read_dynamic_header(LdsStream &L, uint32_t *bp, int6
     b += 14;
     uint32_t i;
     for (i = 0; i < num_precode; i++) {
-        if (!avail(3)) return RSX_SHORT_INPUT;
+        if (!avail(3)) return HeaderResult{RSX_SHORT_INPUT, b};
         L.hdr.precode_lens[c_precode_perm[i]] = fetch_bits(L.win, b) & 7;
         b += 3;
     }
     for (; i < 19; i++) L.hdr.precode_lens[c_precode_perm[i]] = 0;
     if (!build_decode_table(L.hdr.precode, L.hdr.precode_lens, 19, KIND_PRECODE, kPrecodeBits, 7,
-                            L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets))
-        return RSX_BAD_DATA;
+                            L.hdr.sorted_syms, nullptr, L.len_counts, L.offsets))
+        return HeaderResult{RSX_BAD_DATA, b};
     const uint32_t total = num_litlen + num_offset;
     i = 0;
     while (i < total) {
         bits = fetch_bits(L.win, b);
         uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
         uint32_t nbits = e & 0xFF;
-        if (!avail(nbits)) return RSX_SHORT_INPUT;
+        if (!avail(nbits)) return HeaderResult{RSX_SHORT_INPUT, b};
         b += nbits;
         bits >>= nbits;
         uint32_t presym = e >> 16;
@@ -360,7 +366,7 @@ __device__ __noinline__ int read_dynamic_header(LdsStream &L, uint32_t *bp, int6
         }
         uint32_t rep, val, xb;
         if (presym == 16) {
-            if (i == 0) return RSX_BAD_DATA;
+            if (i == 0) return HeaderResult{RSX_BAD_DATA, b};
             val = L.hdr.lens[i - 1];
             xb = 2;
             rep = 3;
@@ -373,20 +379,19 @@ __device__ __noinline__ int read_dynamic_header(LdsStream &L, uint32_t *bp, int6
             xb = 7;
             rep = 11;
         }
-        if (!avail(xb)) return RSX_SHORT_INPUT;
+        if (!avail(xb)) return HeaderResult{RSX_SHORT_INPUT, b};
         rep += bits & ((1u << xb) - 1);
         b += xb;
         // a run passing the end is clamped (src/decompress/mod.rs:462-467)
         while (rep-- && i < total) L.hdr.lens[i++] = (uint8_t)val;
     }
-    *bp = b;
     if (!build_decode_table(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
-                            L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets))
-        return RSX_BAD_DATA;
+                            L.hdr.sorted_syms, nullptr, L.len_counts, L.offsets))
+        return HeaderResult{RSX_BAD_DATA, b};
     if (!build_decode_table(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
-                            L.hdr.sorted_syms, &L.litlen_tablebits, L.hdr.len_counts, L.hdr.offsets))
-        return RSX_BAD_DATA;
-    return RSX_SUCCESS;
+                            L.hdr.sorted_syms, &L.litlen_tablebits, L.len_counts, L.offsets))
+        return HeaderResult{RSX_BAD_DATA, b};
+    return HeaderResult{RSX_SUCCESS, b};
 }
 
 // src/decompress/mod.rs:355-401
@@ -399,9 +404,9 @@ __device__ __noinline__ void load_static_codes(LdsStream &L)
     for (; i < 288; i++) L.hdr.lens[i] = 8;
     for (; i < 320; i++) L.hdr.lens[i] = 5;
     build_decode_table(L.offset, L.hdr.lens + 288, 32, KIND_OFFSET, kOffsetBits, 15, L.hdr.sorted_syms,
-                       nullptr, L.hdr.len_counts, L.hdr.offsets);
+                       nullptr, L.len_counts, L.offsets);
     build_decode_table(L.litlen, L.hdr.lens, 288, KIND_LITLEN, kLitlenBits, 15, L.hdr.sorted_syms,
-                       &L.litlen_tablebits, L.hdr.len_counts, L.hdr.offsets);
+                       &L.litlen_tablebits, L.len_counts, L.offsets);
 }
 
 // Thread-0 part of a round: when the stream is between blocks, read the next
@@ -447,11 +452,12 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
         return;
     }
     if (type == 2) {
-        int r = read_dynamic_header(L, &b, win_bit0, end_bit);
-        if (r != RSX_SUCCESS) {
-            L.status = r;
+        const HeaderResult r = read_dynamic_header(L, b, win_bit0, end_bit);
+        if (r.code != RSX_SUCCESS) {
+            L.status = r.code;
             return;
         }
+        b = r.b;
     } else {
         load_static_codes(L);
     }
@@ -595,7 +601,7 @@ __device__ inline void wg_exclusive_scan2(StreamLds &L, uint32_t a, uint32_t b, 
         L.scan_carry[2 * w] = xa;
         L.scan_carry[2 * w + 1] = xb;
     }
-    __syncthreads();
+    WG_SYNC();
     uint32_t ca = 0, cb = 0;
     for (int k = 0; k < w; k++) {
         ca += L.scan_carry[2 * k];
@@ -603,7 +609,7 @@ __device__ inline void wg_exclusive_scan2(StreamLds &L, uint32_t a, uint32_t b, 
     }
     *ea = ca + xa - a;
     *eb = cb + xb - b;
-    __syncthreads();
+    WG_SYNC();
 }
 
 // All lanes: decode the Huffman block body in the staged window, starting at
@@ -641,11 +647,11 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     L.lane_exit[tid] = sc.exit;
     L.spec.sub_bytes[tid] = (uint16_t)sc.bytes;
     L.spec.sub_nm[tid] = (uint16_t)sc.nm;
-    __syncthreads();
+    WG_SYNC();
     if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tq; tq = t; }
     // the true prefix grows by at least one sub-sequence per pass, so kT passes suffice
     for (int pass = 0; pass <= kT; pass++) {
-        __syncthreads();
+        WG_SYNC();
         uint32_t ns = lo;
         if (tid > 0) {
             uint32_t pe = L.lane_exit[tid - 1];
@@ -659,7 +665,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         if (lane == 0) L.scan_carry[w] = (uint32_t)__popcll(bal);
         if (need) L.spec.sub_start[tid] = start;
         if (RSX_DEV_TIMERS && tid == 0) L.stat_spec++;
-        __syncthreads();
+        WG_SYNC();
         uint32_t before = 0, total = 0;
         for (int k = 0; k < kT / 64; k++) {
             uint32_t cnt = L.scan_carry[k];
@@ -668,7 +674,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         }
         if (total == 0) break;
         if (need) L.spec.work[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)tid;
-        __syncthreads();
+        WG_SYNC();
         if ((uint32_t)tid < total) {
             const uint32_t i = L.spec.work[tid];
             const uint32_t st_i = L.spec.sub_start[i];
@@ -685,11 +691,11 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             L.spec.sub_nm[i] = (uint16_t)r.nm;
         }
     }
-    __syncthreads();
+    WG_SYNC();
     sc.exit = L.lane_exit[tid];
     sc.bytes = L.spec.sub_bytes[tid];
     sc.nm = L.spec.sub_nm[tid];
-    __syncthreads();
+    WG_SYNC();
     if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tq; tq = t; }
     // every start now follows from lane 0's: the first lane that ended the block
     // (or the input) is real, and nothing behind it belongs to this block
@@ -697,9 +703,9 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         L.first_flag = kT;
         L.emit_error = ~0u;
     }
-    __syncthreads();
+    WG_SYNC();
     if (sc.exit & (kExitEob | kExitStop)) atomicMin(&L.first_flag, (uint32_t)tid);
-    __syncthreads();
+    WG_SYNC();
     const bool live = (uint32_t)tid <= L.first_flag;
     if (!live) {
         sc.bytes = 0;
@@ -712,7 +718,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     const bool commit = live && ex_bytes + sc.bytes <= kRoundOut && ex_nm + sc.nm <= kMaxMatches;
     // `commit` is monotone over lanes; the last committed lane publishes the round
     L.lane_exit[tid] = commit ? sc.exit | 0x10000000u : sc.exit;
-    __syncthreads();
+    WG_SYNC();
     const bool last = commit && (tid == kT - 1 || !(L.lane_exit[tid + 1] & 0x10000000u));
 
     if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tq; tq = t; }
@@ -756,7 +762,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         }
         if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
     }
-    __syncthreads();
+    WG_SYNC();
     if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tq; tq = t; }
     if (last) {
         const uint32_t ee = L.emit_error;
@@ -770,7 +776,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             if (L.final_block) L.status = RSX_SUCCESS;
         }
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // All lanes: resolve the queued matches of this round, kCopySub output bytes at a
@@ -792,13 +798,13 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     constexpr uint32_t kSelf = 0xFFFF;
     constexpr uint32_t kBack = 32768;   // pointer value v refers to position sub_start - kBack + v
     uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
-    __syncthreads();
+    WG_SYNC();
     for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub) {
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         const uint32_t n = sub_end - sub_start;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
         for (uint32_t i = tid; i < n; i += kT) ptr[i] = (uint16_t)kSelf;
-        __syncthreads();
+        WG_SYNC();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
         uint32_t consumed = 0;
         for (uint32_t m = mcur + tid; m < nm; m += kT) {
@@ -813,31 +819,44 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (uint32_t pos = from; pos < to; pos++) ptr[pos - sub_start] = (uint16_t)(pos + bias);
             if (dst + len <= sub_end) consumed++;
         }
-        if (RSX_DEV_TIMERS == 2) { __syncthreads(); if (tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; } }
+        if (RSX_DEV_TIMERS == 2) { WG_SYNC(); if (tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; } }
         // advance mcur by the number of matches that end inside this step
         {
             uint32_t x = consumed;
             for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
             if ((tid & 63) == 0) L.scan_carry[tid >> 6] = x;
         }
-        __syncthreads();
+        WG_SYNC();
         for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tc; tc = t; }
         // pointer jumping: a pointer into this step that lands on a non-literal byte
         // takes over that byte's pointer
         constexpr int kPer = kCopySub / kT;
+        // (all reads of a round are issued before the first dependent one is needed)
         for (int round = 0; round < 16; round++) {
             bool changed = false;
-            for (uint32_t i = tid; i < n; i += kT) {
-                const uint32_t v = ptr[i];
-                if (v != kSelf && v >= kBack) {
-                    const uint32_t v2 = ptr[v - kBack];
-                    if (v2 != kSelf) {
-                        ptr[i] = (uint16_t)v2;
-                        changed = true;
-                    }
+            uint32_t v[kPer], v2[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const uint32_t i = tid + k * kT;
+                v[k] = i < n ? ptr[i] : kSelf;
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const bool hop = v[k] != kSelf && v[k] >= kBack;
+                v2[k] = hop ? ptr[v[k] - kBack] : kSelf;
+            }
+            WG_SYNC();   // every read of this round precedes its writes
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                if (v2[k] != kSelf) {
+                    ptr[tid + k * kT] = (uint16_t)v2[k];
+                    // a pointer that now leaves the step is final; only one that still
+                    // points into the step can need another round
+                    changed = changed || v2[k] >= kBack;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!__syncthreads_or(changed)) break;
         }
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
@@ -856,17 +875,24 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
                 byte[k] = 0;
                 if (v[k] != kSelf) {
                     const int64_t sp = (int64_t)sub_start - kBack + v[k];
-                    byte[k] = sp >= lds_lo ? L.ring[((uint32_t)sp + c.shift) & kRingMask] : c.out[sp];
+                    // two separate reads: written as one conditional expression the compiler
+                    // folds them into a single FLAT load whose address is either in LDS or in
+                    // global memory
+                    const uint8_t in_ring = L.ring[((uint32_t)sp + c.shift) & kRingMask];
+                    uint8_t far_byte = 0;
+                    if (sp < lds_lo)
+                        far_byte = *((const __attribute__((address_space(1))) uint8_t *)c.out + sp);
+                    byte[k] = sp >= lds_lo ? in_ring : far_byte;
                 }
             }
 #pragma unroll
             for (int k = 0; k < kPer; k++)
                 if (v[k] != kSelf) L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = byte[k];
         }
-        __syncthreads();
+        WG_SYNC();
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tc; tc = t; }
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // All lanes: write output positions [from, to) from the ring to global memory.
@@ -874,7 +900,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
 // 16-byte stores, the ragged first / last unit byte stores.
 __device__ void flush_range(StreamLds &L, const StreamCtx &c, uint32_t from, uint32_t to)
 {
-    if (to <= from) return;
+    if (to <= from) return;   // (uniform)
     const uint32_t g_from = from + c.shift, g_to = to + c.shift;  // = global address mod-16 phase
     const uint32_t u0 = g_from >> 4, u1 = (g_to + 15) >> 4;
     for (uint32_t u = u0 + threadIdx.x; u < u1; u += kT) {
@@ -1004,7 +1030,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
     uint32_t flushed = 0;  // output positions below this are in global memory (uniform)
     uint64_t seen_bitpos = ~0ull;  // progress watchdog (uniform)
     int stalled = 0;
-    __syncthreads();
+    WG_SYNC();
 
     for (;;) {
         // every round either consumes input or moves the window; anything else is a bug
@@ -1013,31 +1039,31 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
             const uint64_t bp = L.bitpos;
             stalled = bp == seen_bitpos ? stalled + 1 : 0;
             seen_bitpos = bp;
-            __syncthreads();
+            WG_SYNC();
             if (stalled > 4) {
                 if (tid == 0) L.status = RSX_BAD_DATA;
-                __syncthreads();
+                WG_SYNC();
                 break;
             }
         }
         int64_t win_bit0;
         STAT_BEGIN();
         stage_window(L, c, &win_bit0);
-        __syncthreads();
+        WG_SYNC();
         STAT_END(tS);
         nRounds++;
         if (!L.in_block) {
             STAT_BEGIN();
-            __syncthreads();
+            WG_SYNC();
             if (tid == 0) header_step(*(LdsStream *)&L, c, win_bit0);
-            __syncthreads();
+            WG_SYNC();
             STAT_END(tH);
         }
         {
             // snapshot the control block, then let nobody change it before all have read it
             const int restage = L.restage, st0 = L.status, stored0 = L.stored_len;
             const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
-            __syncthreads();
+            WG_SYNC();
             if (restage) {  // the window has to move to the block header first
                 if (tid == 0) L.restage = 0;
                 continue;
@@ -1057,7 +1083,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
         const uint32_t round_end = L.round_end_lo;
         int st = L.status;
         int32_t stored = L.stored_len;
-        __syncthreads();
+        WG_SYNC();
         if (st < 0 && stored >= 0) {
             // stored block body (src/decompress/mod.rs:305-346): first push out what
             // the round produced, then move the bytes in ring-sized pieces
@@ -1080,7 +1106,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
                     uint32_t piece = len - done < kRoundOut ? len - done : kRoundOut;
                     for (uint32_t k = tid; k < piece; k += kT)
                         L.ring[(pos + k + c.shift) & kRingMask] = sp[done + k];
-                    __syncthreads();
+                    WG_SYNC();
                     pos += piece;
                     done += piece;
                     uint32_t up2 = ((pos + c.shift) & ~15u);
@@ -1088,11 +1114,11 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
                     if (up2 < flushed) up2 = flushed;
                     flush_range(L, c, flushed, up2);
                     flushed = up2;
-                    __syncthreads();
+                    WG_SYNC();
                 }
                 if (L.final_block) st = RSX_SUCCESS;
             }
-            __syncthreads();
+            WG_SYNC();
             if (tid == 0) {
                 L.stored_len = -1;
                 L.bitpos += (uint64_t)len * 8;
@@ -1100,7 +1126,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
                 L.round_end_lo = pos;
                 L.status = st;
             }
-            __syncthreads();
+            WG_SYNC();
             if (st >= 0) break;
             continue;
         }
@@ -1112,7 +1138,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
         flush_range(L, c, flushed, upto);
         flushed = upto;
         if (tid == 0) L.round_start_lo = round_end;
-        __syncthreads();
+        WG_SYNC();
         STAT_END(tF);
     }
 
