@@ -98,7 +98,7 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     out_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(bound)
     d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
     d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
-    d_out = torch.empty(n * bound, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(n * bound, dtype=torch.uint8, device=dev)
     d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
     d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
     eng = rsx.Engine(local_rank, torch.cuda.current_stream(dev).cuda_stream)
@@ -130,6 +130,10 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     st = d_status.cpu().numpy()
     sz = d_sizes.cpu().numpy()
     ok = bool((st == 0).all())
+    if n > distinct:  # every replica of an input must carry the same bytes as its original
+        rows = d_out.view(n, bound)
+        ok = ok and bool((rows[distinct:] == rows[:n - distinct]).all())
+        ok = ok and bool((sz[distinct:] == sz[:n - distinct]).all())
     for i in range(distinct):  # the oracle must inflate every distinct stream to its input
         c = d_out[i * bound: i * bound + int(sz[i])].cpu().numpy().tobytes()
         r, _, back = orc.decompress(c, buf, ofmt)

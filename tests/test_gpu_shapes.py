@@ -116,3 +116,28 @@ def test_repeated_full_occupancy_batches(eng, rsx):
         assert len(bad) == 0, (it, bad[:8], st[bad[:8]])
     for i in (0, 17, 4095):
         assert d_out[i * buf:(i + 1) * buf].cpu().numpy().tobytes() == distinct[i % 16]
+
+
+def test_repeated_compress_batches_are_identical(eng):
+    # the compressor under full occupancy: replicas of the same input must give the same
+    # bytes in every slot and every call, and those bytes must inflate to the input
+    datas = [corpus.mixed(1 << 18, 600 + i) for i in range(16)]
+    n = 2048
+    items = [datas[i % 16] for i in range(n)]
+    first = None
+    for _ in range(3):
+        comp, st = eng.batch_compress(items, 0, 6)
+        assert (np.asarray(st) == 0).all()
+        for i in range(16, n):
+            assert comp[i] == comp[i % 16], i
+        if first is None:
+            first = comp[:16]
+        assert comp[:16] == first
+    for i in range(16):
+        assert zlib.decompress(first[i], -15) == datas[i]
+    comp12, st = eng.batch_compress(items[:256], 0, 12)
+    assert (np.asarray(st) == 0).all()
+    for i in range(16, 256):
+        assert comp12[i] == comp12[i % 16], i
+    for i in range(16):
+        assert zlib.decompress(comp12[i], -15) == datas[i]
