@@ -31,6 +31,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 
+def measured_traffic(key):
+    """HBM bytes per launch of the dominant kernel for the default workloads, taken from
+    separate rocprofv3 --pmc passes (counters cannot be collected inside a timed run);
+    None for any other configuration."""
+    try:
+        with open(os.path.join(ROOT, "bench_traffic.json")) as f:
+            return json.load(f).get(key)
+    except OSError:
+        return None
+
+
 def host_threads():
     try:
         avail = len(os.sched_getaffinity(0))
@@ -165,7 +176,8 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
                        "buf_bytes": buf, "distinct_buffers": distinct,
                        "compressed_ratio": total_in / total_out, "verified": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level)),
                          "kernel": "deflate_chunks_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes": total_in + total_out},
         }
@@ -344,7 +356,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level)),
                 "kernel": "inflate_kernel", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
             },
         }
