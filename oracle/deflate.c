@@ -1,10 +1,11 @@
 /*
  * deflate.c -- raw DEFLATE / zlib / gzip compression restated on the CPU for
- * levels 0-9 (oracle; test infrastructure only, see rsx_oracle.h).
+ * levels 0-12 (oracle; test infrastructure only, see rsx_oracle.h).
  *
- * Follows src/compress/mod.rs (driver, greedy/lazy parse, block splitting,
- * dynamic header, sequence writer), src/compress/matchfinder.rs (hash-chain and
- * single-probe hash-table match finders) and src/compress/huffman_comp.rs
+ * Follows src/compress/mod.rs (driver, greedy/lazy parse, near-optimal parse of
+ * levels 10-12, block splitting, dynamic header, sequence writer),
+ * src/compress/matchfinder.rs (hash-chain, single-probe hash-table and
+ * binary-tree match finders) and src/compress/huffman_comp.rs
  * (length-limited canonical Huffman code).  Like the reference it has no
  * stored-block fallback above level 0: a stream that does not fit the output
  * buffer reports InsufficientSpace (src/compress/mod.rs:641-644).
@@ -310,6 +311,10 @@ static int should_end_block(split_stats *s, size_t block_len, size_t remaining)
 
 /* ---- compressor state ---------------------------------------------------- */
 
+#define BT_HASH_SIZE (1u << 16)   /* matchfinder.rs:1319-1320 */
+#define DP_CAP 300000u            /* hard cap of a block, mod.rs:278-416 */
+#define BT_MAX_MATCHES 512u       /* a position reports at most one match per length */
+
 typedef struct {
     uint32_t litrunlen;
     uint16_t length; /* len | offset_slot << 9 */
@@ -328,6 +333,13 @@ struct orc_compressor {
     sequence *seqs;
     size_t nseq, seq_cap;
     split_stats stats;
+    /* levels 10-12 (src/compress/mod.rs:478-503) */
+    int32_t (*bt_hash3)[2];
+    int32_t *bt_hash4;
+    int32_t (*bt_child)[2];
+    uint32_t *dp_costs, *dp_path;
+    uint16_t (*matches)[2];
+    uint32_t length_costs[MAX_MATCH + 1], offset_slot_costs[NUM_OFFSET];
 };
 
 /* src/compress/mod.rs:543-602 */
@@ -342,17 +354,33 @@ static void init_params(orc_compressor *c)
 
 orc_compressor *orc_compressor_new(int level)
 {
-    if (level < 0 || level >= 10)
-        return NULL; /* levels 10-12 (near-optimal parse) are not restated here */
+    if (level < 0 || level > 12) return NULL;
     if (!__atomic_load_n(&tabs_ready, __ATOMIC_ACQUIRE)) init_tabs();
     orc_compressor *c = calloc(1, sizeof(*c));
     if (!c) return NULL;
     c->level = level;
     init_params(c);
-    c->hash_tab = malloc(HASH_SIZE * sizeof(int32_t));
-    c->prev_tab = calloc(WINDOW_SIZE, sizeof(uint16_t));
     c->seq_cap = 50000; /* src/compress/mod.rs:486 */
     c->seqs = malloc(c->seq_cap * sizeof(sequence));
+    if (level >= 10) {
+        /* matchfinder.rs:1317-1325, mod.rs:488-503 */
+        c->bt_hash3 = malloc(BT_HASH_SIZE * sizeof(*c->bt_hash3));
+        c->bt_hash4 = malloc(BT_HASH_SIZE * sizeof(int32_t));
+        c->bt_child = calloc(WINDOW_SIZE, sizeof(*c->bt_child));
+        c->dp_costs = malloc((DP_CAP + 1) * sizeof(uint32_t));
+        c->dp_path = malloc((DP_CAP + 1) * sizeof(uint32_t));
+        c->matches = malloc(BT_MAX_MATCHES * sizeof(*c->matches));
+        if (!c->bt_hash3 || !c->bt_hash4 || !c->bt_child || !c->dp_costs || !c->dp_path ||
+            !c->matches || !c->seqs) {
+            orc_compressor_free(c);
+            return NULL;
+        }
+        memset(c->bt_hash3, 0xFF, BT_HASH_SIZE * sizeof(*c->bt_hash3));
+        memset(c->bt_hash4, 0xFF, BT_HASH_SIZE * sizeof(int32_t));
+        return c;
+    }
+    c->hash_tab = malloc(HASH_SIZE * sizeof(int32_t));
+    c->prev_tab = calloc(WINDOW_SIZE, sizeof(uint16_t));
     if (!c->hash_tab || !c->prev_tab || !c->seqs) {
         orc_compressor_free(c);
         return NULL;
@@ -367,6 +395,12 @@ void orc_compressor_free(orc_compressor *c)
     free(c->hash_tab);
     free(c->prev_tab);
     free(c->seqs);
+    free(c->bt_hash3);
+    free(c->bt_hash4);
+    free(c->bt_child);
+    free(c->dp_costs);
+    free(c->dp_path);
+    free(c->matches);
     free(c);
 }
 
@@ -526,6 +560,148 @@ void orc_hc_find_match_kat(const uint8_t *data, size_t len, size_t pos, int max_
     *out_len = (int)hc_find_match(c, data, len, pos, &off);
     *out_offset = (int)off;
     orc_compressor_free(c);
+}
+
+/* ---- binary-tree match finder (src/compress/matchfinder.rs:1308-1776) ---- */
+
+enum { VIS_BEST, VIS_ALL, VIS_NONE };
+typedef struct {
+    int kind;
+    unsigned best_len, best_off; /* VIS_BEST: matchfinder.rs:1239-1267; VIS_ALL starts at 3 (:1274-1281) */
+    uint16_t (*matches)[2];
+    unsigned nmatches;
+} bt_visitor;
+
+static inline void vis_hash3(bt_visitor *v, unsigned len, unsigned off)
+{
+    if (v->kind == VIS_BEST) { /* matchfinder.rs:1255-1258 */
+        v->best_len = len;
+        v->best_off = off;
+    } else if (v->kind == VIS_ALL) { /* :1285-1287 */
+        v->matches[v->nmatches][0] = (uint16_t)len;
+        v->matches[v->nmatches][1] = (uint16_t)off;
+        v->nmatches++;
+    }
+}
+
+static inline void vis_match(bt_visitor *v, unsigned len, unsigned off)
+{
+    if (v->kind == VIS_NONE) return;
+    if (len > v->best_len) { /* :1261-1266, :1290-1295 */
+        v->best_len = len;
+        v->best_off = off;
+        if (v->kind == VIS_ALL) {
+            v->matches[v->nmatches][0] = (uint16_t)len;
+            v->matches[v->nmatches][1] = (uint16_t)off;
+            v->nmatches++;
+        }
+    }
+}
+
+static void bt_reset(orc_compressor *c) /* matchfinder.rs:1327-1331 */
+{
+    memset(c->bt_hash3, 0xFF, BT_HASH_SIZE * sizeof(*c->bt_hash3));
+    memset(c->bt_hash4, 0xFF, BT_HASH_SIZE * sizeof(int32_t));
+    c->base_offset = 0;
+}
+
+/* matchfinder.rs:1344-1463 */
+static void bt_advance_one_byte(orc_compressor *c, const uint8_t *data, size_t data_len, size_t pos,
+                                unsigned max_len, unsigned nice_len, unsigned max_depth,
+                                bt_visitor *v)
+{
+    if (pos + 4 > data_len) return;
+    const uint8_t *src = data + pos;
+    uint32_t val = src[0] | (src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
+    uint32_t h3 = ((val & 0xFFFFFFu) * 0x1E35A7BDu) >> 16;
+    uint32_t h4 = (val * 0x1E35A7BDu) >> 16;
+    size_t abs_pos = c->base_offset + pos;
+
+    int32_t cur_node_3 = c->bt_hash3[h3][0];
+    c->bt_hash3[h3][0] = (int32_t)abs_pos;
+    int32_t cur_node_3_2 = c->bt_hash3[h3][1];
+    c->bt_hash3[h3][1] = cur_node_3;
+
+    int32_t cutoff = (int32_t)abs_pos - (int32_t)WINDOW_SIZE;
+
+    if (cur_node_3 != -1 && cur_node_3 > cutoff && (size_t)cur_node_3 >= c->base_offset) {
+        const uint8_t *m = data + ((size_t)cur_node_3 - c->base_offset);
+        if (m[0] == src[0] && m[1] == src[1] && m[2] == src[2]) {
+            vis_hash3(v, 3, (unsigned)(abs_pos - (size_t)cur_node_3));
+        } else if (cur_node_3_2 != -1 && cur_node_3_2 > cutoff &&
+                   (size_t)cur_node_3_2 >= c->base_offset) {
+            const uint8_t *m2 = data + ((size_t)cur_node_3_2 - c->base_offset);
+            if (m2[0] == src[0] && m2[1] == src[1] && m2[2] == src[2])
+                vis_hash3(v, 3, (unsigned)(abs_pos - (size_t)cur_node_3_2));
+        }
+    }
+
+    int32_t cur_node = c->bt_hash4[h4];
+    c->bt_hash4[h4] = (int32_t)abs_pos;
+    size_t child_idx = abs_pos & (WINDOW_SIZE - 1);
+    if (cur_node == -1 || cur_node <= cutoff || (size_t)cur_node < c->base_offset) {
+        c->bt_child[child_idx][0] = -1;
+        c->bt_child[child_idx][1] = -1;
+        return;
+    }
+    unsigned depth_remaining = max_depth;
+    size_t pending_lt_node = child_idx, pending_gt_node = child_idx;
+    int pending_lt_child = 0, pending_gt_child = 1;
+    unsigned max_len_clamped = max_len < data_len - pos ? max_len : (unsigned)(data_len - pos);
+    for (;;) {
+        size_t p_abs = (size_t)cur_node;
+        size_t p_child_idx = p_abs & (WINDOW_SIZE - 1);
+        const uint8_t *m = data + (p_abs - c->base_offset);
+        unsigned len = match_len(m, src, max_len_clamped);
+        vis_match(v, len, (unsigned)(abs_pos - p_abs));
+        if (len >= nice_len || len == max_len_clamped) {
+            int32_t c0 = c->bt_child[p_child_idx][0], c1 = c->bt_child[p_child_idx][1];
+            c->bt_child[pending_lt_node][pending_lt_child] = c0;
+            c->bt_child[pending_gt_node][pending_gt_child] = c1;
+            return;
+        }
+        if (len < max_len_clamped && m[len] < src[len]) {
+            c->bt_child[pending_lt_node][pending_lt_child] = cur_node;
+            pending_lt_node = p_child_idx;
+            pending_lt_child = 1;
+            cur_node = c->bt_child[p_child_idx][1];
+        } else {
+            c->bt_child[pending_gt_node][pending_gt_child] = cur_node;
+            pending_gt_node = p_child_idx;
+            pending_gt_child = 0;
+            cur_node = c->bt_child[p_child_idx][0];
+        }
+        if (cur_node == -1 || cur_node <= cutoff || (size_t)cur_node < c->base_offset ||
+            --depth_remaining == 0) {
+            c->bt_child[pending_lt_node][pending_lt_child] = -1;
+            c->bt_child[pending_gt_node][pending_gt_child] = -1;
+            return;
+        }
+    }
+}
+
+static unsigned bt_find_match(orc_compressor *c, const uint8_t *data, size_t data_len, size_t pos,
+                              unsigned *off) /* matchfinder.rs:1465-1531 */
+{
+    bt_visitor v = {VIS_BEST, 0, 0, NULL, 0};
+    bt_advance_one_byte(c, data, data_len, pos, MAX_MATCH, c->nice_len, c->max_depth, &v);
+    *off = v.best_off;
+    return v.best_len;
+}
+
+static void bt_skip_positions(orc_compressor *c, const uint8_t *data, size_t data_len, size_t pos,
+                              size_t count) /* matchfinder.rs:1606-1701 */
+{
+    bt_visitor v = {VIS_NONE, 0, 0, NULL, 0};
+    for (size_t k = 0; k < count; k++)
+        bt_advance_one_byte(c, data, data_len, pos + k, MAX_MATCH, c->nice_len, c->max_depth, &v);
+}
+
+static unsigned bt_find_matches(orc_compressor *c, const uint8_t *data, size_t data_len, size_t pos)
+{ /* matchfinder.rs:1703-1775; returns the number of matches left in c->matches */
+    bt_visitor v = {VIS_ALL, 3, 0, c->matches, 0};
+    bt_advance_one_byte(c, data, data_len, pos, MAX_MATCH, c->nice_len, c->max_depth, &v);
+    return v.nmatches;
 }
 
 /* ---- parsing ------------------------------------------------------------- */
@@ -764,6 +940,131 @@ static size_t compress_greedy_block(orc_compressor *c, const uint8_t *in, size_t
     return processed;
 }
 
+/* src/compress/mod.rs:1586-1773.  Returns bytes consumed, 0 on overflow. */
+static size_t compress_near_optimal_block(orc_compressor *c, const uint8_t *in, size_t n,
+                                          size_t start, bitw *w, int final_block)
+{
+    /* pass 1: greedy parse with the binary tree, for the block end and first statistics */
+    memset(&c->stats, 0, sizeof(c->stats));
+    memset(c->litlen_freqs, 0, sizeof(c->litlen_freqs));
+    memset(c->offset_freqs, 0, sizeof(c->offset_freqs));
+    size_t in_idx = start;
+    while (in_idx < n) {
+        if (should_end_block(&c->stats, in_idx - start, n - in_idx)) break;
+        unsigned off, len = bt_find_match(c, in, n, in_idx, &off);
+        if (len >= 3) {
+            unsigned slot = offset_slot(off);
+            observe_match(&c->stats, len, slot);
+            c->litlen_freqs[257 + length_slot_tab[len]]++;
+            c->offset_freqs[slot]++;
+            bt_skip_positions(c, in, n, in_idx + 1, len - 1);
+            in_idx += len;
+        } else {
+            observe_literal(&c->stats, in[in_idx]);
+            c->litlen_freqs[in[in_idx]]++;
+            in_idx++;
+        }
+    }
+    const size_t processed = in_idx - start;
+    const uint8_t *block = in + start;
+    const int is_final = (start + processed >= n) && final_block;
+
+    c->nseq = 0;
+    c->litlen_freqs[256]++;
+    make_huffman_code(NUM_LITLEN, MAX_LITLEN_CODEWORD_LEN, c->litlen_freqs, c->litlen_lens,
+                      c->litlen_codes);
+    make_huffman_code(NUM_OFFSET, MAX_OFFSET_CODEWORD_LEN, c->offset_freqs, c->offset_lens,
+                      c->offset_codes);
+    /* update_costs, mod.rs:2209-2224: unused symbols cost 0 bits, as in the reference */
+    for (unsigned len = 3; len <= MAX_MATCH; len++) {
+        unsigned ls = length_slot_tab[len];
+        c->length_costs[len] = c->litlen_lens[257 + ls] + length_extra[ls];
+    }
+    for (unsigned slot = 0; slot < 30; slot++)
+        c->offset_slot_costs[slot] = c->offset_lens[slot] + offset_extra[slot];
+
+    for (size_t i = 0; i <= processed; i++) c->dp_costs[i] = 0x3FFFFFFFu;
+    c->dp_costs[0] = 0;
+
+    /* pass 2: forward relaxation over the block slice with a fresh match finder */
+    bt_reset(c);
+    size_t pos = 0;
+    while (pos < processed) {
+        uint32_t cur = c->dp_costs[pos];
+        if (cur >= 0x3FFFFFFFu) {
+            pos++;
+            continue;
+        }
+        uint32_t lit = c->litlen_lens[block[pos]];
+        if (cur + lit < c->dp_costs[pos + 1]) {
+            c->dp_costs[pos + 1] = cur + lit;
+            c->dp_path[pos + 1] = 1;
+        }
+        unsigned nm = bt_find_matches(c, block, processed, pos);
+        unsigned best_len = 0;
+        for (unsigned k = 0; k < nm; k++) {
+            unsigned len = c->matches[k][0], off = c->matches[k][1];
+            if (len > best_len) best_len = len;
+            unsigned real_off = off; /* 1..32768 fits the reference's u16 */
+            uint32_t cost = c->length_costs[len] + c->offset_slot_costs[offset_slot(real_off)];
+            if (cur + cost < c->dp_costs[pos + len]) {
+                c->dp_costs[pos + len] = cur + cost;
+                c->dp_path[pos + len] = len | ((uint32_t)real_off << 16);
+            }
+        }
+        if (best_len >= c->nice_len) {
+            bt_skip_positions(c, block, processed, pos + 1, best_len - 1);
+            pos += best_len;
+        } else {
+            pos++;
+        }
+    }
+
+    /* backtrack, then rebuild statistics and sequences in forward order (mod.rs:1719-1751) */
+    memset(c->litlen_freqs, 0, sizeof(c->litlen_freqs));
+    memset(c->offset_freqs, 0, sizeof(c->offset_freqs));
+    c->litlen_freqs[256] = 1;
+    size_t nnodes = 0;
+    for (size_t p = processed; p > 0;) {
+        uint32_t packed = c->dp_path[p];
+        /* node list reuses dp_costs from the top: every cost below p is dead once visited */
+        c->dp_costs[processed - nnodes] = packed;
+        nnodes++;
+        p -= packed & 0xFFFF;
+    }
+    uint32_t litrunlen = 0;
+    size_t cur_pos = 0;
+    for (size_t k = nnodes; k-- > 0;) {
+        uint32_t packed = c->dp_costs[processed - k];
+        unsigned length = packed & 0xFFFF, offset = packed >> 16;
+        if (length == 1) {
+            c->litlen_freqs[block[cur_pos]]++;
+            litrunlen++;
+            cur_pos++;
+        } else {
+            unsigned slot = offset_slot(offset);
+            push_seq(c, litrunlen, length, offset, slot);
+            c->litlen_freqs[257 + length_slot_tab[length]]++;
+            c->offset_freqs[slot]++;
+            litrunlen = 0;
+            cur_pos += length;
+        }
+    }
+    push_seq(c, litrunlen, 0, 0, 0);
+    make_huffman_code(NUM_LITLEN, MAX_LITLEN_CODEWORD_LEN, c->litlen_freqs, c->litlen_lens,
+                      c->litlen_codes);
+    make_huffman_code(NUM_OFFSET, MAX_OFFSET_CODEWORD_LEN, c->offset_freqs, c->offset_lens,
+                      c->offset_codes);
+    /* write_dynamic_block_with_sequences, mod.rs:1375-1398 */
+    bw_put(w, is_final, 1);
+    bw_put(w, 2, 2);
+    write_dynamic_header(c, w);
+    write_sequences(c, w, in, start);
+    bw_put(w, c->litlen_codes[256], c->litlen_lens[256]);
+    if (w->overflow) return 0;
+    return processed;
+}
+
 /* src/compress/mod.rs:1400-1464 */
 static int compress_uncompressed(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int flush,
                                  size_t *out_len)
@@ -800,16 +1101,19 @@ static int compress_chunk(orc_compressor *c, const uint8_t *in, size_t n, uint8_
 {
     if (c->level == 0) return compress_uncompressed(in, n, out, cap, flush, out_len);
     bitw w = {out, cap, 0, 0, 0, 0};
-    /* matchfinder.rs:743-747 */
+    /* matchfinder.rs:743-747, :1333-1337 */
     if (c->base_offset + n > 0x7FFFFFFFu) {
-        memset(c->hash_tab, 0xFF, HASH_SIZE * sizeof(int32_t));
+        if (c->level >= 10) bt_reset(c);
+        else memset(c->hash_tab, 0xFF, HASH_SIZE * sizeof(int32_t));
         c->base_offset = 0;
     }
     unsigned lazy = c->level >= 8 ? 2 : c->level >= 5 ? 1 : 0;
     size_t i = 0;
     int fail = 0;
     while (i < n) {
-        size_t p = compress_greedy_block(c, in, n, i, &w, lazy, flush == ORC_FLUSH_FINISH);
+        size_t p = c->level >= 10
+                       ? compress_near_optimal_block(c, in, n, i, &w, flush == ORC_FLUSH_FINISH)
+                       : compress_greedy_block(c, in, n, i, &w, lazy, flush == ORC_FLUSH_FINISH);
         if (p == 0) {
             fail = 1;
             break;
@@ -817,7 +1121,8 @@ static int compress_chunk(orc_compressor *c, const uint8_t *in, size_t n, uint8_
         i += p;
     }
     if (!fail && n == 0 && flush == ORC_FLUSH_FINISH) {
-        compress_greedy_block(c, in, 0, 0, &w, 0, 1);
+        if (c->level >= 10) compress_near_optimal_block(c, in, 0, 0, &w, 1);
+        else compress_greedy_block(c, in, 0, 0, &w, 0, 1);
         if (w.overflow) fail = 1;
     }
     if (!fail && flush == ORC_FLUSH_SYNC) {

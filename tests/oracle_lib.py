@@ -94,7 +94,7 @@ def compress(data, level=6, fmt=FMT_DEFLATE, out_cap=None):
     L = lib()
     c = L.orc_compressor_new(level)
     if not c:
-        raise ValueError("level %d not restated by the oracle" % level)
+        raise ValueError("compression level %d is outside 0..12" % level)
     try:
         a, p = _buf(data)
         cap = compress_bound(fmt, len(data)) if out_cap is None else out_cap

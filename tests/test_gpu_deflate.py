@@ -106,17 +106,19 @@ def test_level_ordering_and_ratio_vs_oracle(eng):
 
 def test_cost_based_levels(eng):
     # levels 10-12 (src/compress/mod.rs:1586-1773): valid streams in every format, no larger
-    # than the lazy parse with the deepest search, and smaller than the reference's level 9
-    # (the oracle has no restatement of the reference's levels 10-12 to compare against)
+    # than the lazy parse with the deepest search, and within 3 % of the oracle's restatement
+    # of the reference's near-optimal parse at the same level (the engine prices every prefix
+    # of every recorded match, the reference only whole matches: it is usually smaller)
     datas = [corpus.json_like(1 << 20, 21), corpus.text(700000, 22), corpus.mixed(300000, 23),
              corpus.text(8191, 24), corpus.text(8193, 25), b"abcabcabc" * 5000, corpus.random_bytes(70000, 26)]
     l9, _ = eng.batch_compress(datas, 0, 9)
     for level in (10, 11, 12):
         comp = roundtrip(eng, datas, 0, level)
-        if level == 12:
-            for d, c, c9 in zip(datas[:3], comp, l9):
+        for d, c, c9 in zip(datas[:3], comp, l9):
+            ref = o.compress(d, level)
+            assert len(c) <= 1.03 * len(ref), (level, len(c), len(ref))
+            if level == 12:
                 assert len(c) <= len(c9), (len(c), len(c9))
-                assert len(c) < len(o.compress(d, 9))
     roundtrip(eng, datas[:3], 1, 12)
     roundtrip(eng, datas[:3], 2, 10)
 

@@ -178,3 +178,25 @@ def test_incompressible_fails_like_reference():
     # no stored-block fallback above level 0 (src/compress/mod.rs:1475-1496):
     # random bytes do not fit deflate_compress_bound and report InsufficientSpace
     assert o.compress(os.urandom(65536), 6, o.FMT_DEFLATE) is None
+
+
+def test_near_optimal_levels():
+    # levels 10-12 (src/compress/mod.rs:1586-1773): streams valid for zlib and for the oracle's
+    # own inflater, no larger than level 9 on compressible data, and the reference's own
+    # ordering test (tests/unit_tests.rs:112-125)
+    import corpus
+    datas = [corpus.json_like(300000, 31), corpus.text(300000, 32), corpus.mixed(300000, 33), b"",
+             b"a", b"abcabcabc" * 3000, bytes(70000), corpus.text(262144 + 5000, 34)]
+    for lvl in (10, 11, 12):
+        for d in datas:
+            c = o.compress(d, lvl)
+            assert c is not None
+            assert zlib.decompress(c, -15) == d
+            assert o.decompress(c, len(d), o.FMT_DEFLATE) == (o.SUCCESS, len(c), d)
+    for d in datas[:3]:
+        assert len(o.compress(d, 12)) <= len(o.compress(d, 9))
+    a = b"a" * 10000
+    assert len(o.compress(a, 0)) > 10000
+    assert len(o.compress(a, 12)) <= len(o.compress(a, 1)) < len(o.compress(a, 0))
+    for fmt, wb in ((o.FMT_ZLIB, 15), (o.FMT_GZIP, 31)):
+        assert zlib.decompress(o.compress(datas[0], 12, fmt), wb) == datas[0]
