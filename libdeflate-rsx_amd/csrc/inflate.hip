@@ -53,7 +53,7 @@ constexpr uint32_t kWinWords = kWinBytes / 4;
 // a token may start only while two dwords past its last fetch are still staged:
 // litlen fetch at b, offset fetch at most 20 bits later, each reads words w, w+1
 constexpr uint32_t kWinLimitBits = (kWinWords - 2) * 32 - 20;
-constexpr uint32_t kSubBits = 120;            // compressed bits per lane and round
+constexpr uint32_t kSubBits = 126;            // compressed bits per lane and round
 // one lane decodes at most kSubBits/2 matches of 258 bytes (a match token is
 // at least 2 bits), so a round that commits at least lane 0 always fits
 constexpr uint32_t kRoundOut = 16384 - 16;    // output bytes per round
