@@ -803,13 +803,17 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         const uint32_t n = sub_end - sub_start;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
-        for (uint32_t i = tid; i < n; i += kT) ptr[i] = (uint16_t)kSelf;
+        static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
+        reinterpret_cast<uint4 *>(ptr)[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
         WG_SYNC();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
-        uint32_t consumed = 0;
+        // The lane that sees the last match ending inside this step publishes the next
+        // step's mcur (matches do not overlap, so "ends inside" is monotone).
         for (uint32_t m = mcur + tid; m < nm; m += kT) {
             const uint32_t q = L.mq.dl[m];
             const uint32_t dst = round_start + (q & 0x7FFF), len = q >> 15;
+            const bool ends_here = dst + len <= sub_end;
+            if (m == mcur && !ends_here) L.scan_carry[0] = mcur;
             if (dst >= sub_end) break;
             const uint32_t dist = (uint32_t)L.mq.dist[m] + 1;
             const uint32_t from = dst > sub_start ? dst : sub_start;
@@ -817,59 +821,61 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             // source position p - dist, encoded relative to sub_start - kBack
             const uint32_t bias = kBack - dist - sub_start;
             for (uint32_t pos = from; pos < to; pos++) ptr[pos - sub_start] = (uint16_t)(pos + bias);
-            if (dst + len <= sub_end) consumed++;
-        }
-        if (RSX_DEV_TIMERS == 2) { WG_SYNC(); if (tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; } }
-        // advance mcur by the number of matches that end inside this step
-        {
-            uint32_t x = consumed;
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if ((tid & 63) == 0) L.scan_carry[tid >> 6] = x;
+            if (ends_here) {
+                bool next_ends = false;
+                if (m + 1 < nm) {
+                    const uint32_t q1 = L.mq.dl[m + 1];
+                    next_ends = round_start + (q1 & 0x7FFF) + (q1 >> 15) <= sub_end;
+                }
+                if (!next_ends) L.scan_carry[0] = m + 1;
+            }
         }
         WG_SYNC();
-        for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
-        if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[1] += t - tc; tc = t; }
-        // pointer jumping: a pointer into this step that lands on a non-literal byte
-        // takes over that byte's pointer
+        mcur = L.scan_carry[0];
+        if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; }
+        // Pointer jumping: a pointer into this step that lands on a non-literal byte takes
+        // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
+        // registers; `pend` marks the ones that may still move.  A pointer is final once it
+        // leaves the step or lands on a literal.
         constexpr int kPer = kCopySub / kT;
-        // (all reads of a round are issued before the first dependent one is needed)
+        uint32_t v[kPer];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const uint32_t i = tid + k * kT;
+            v[k] = i < n ? ptr[i] : kSelf;
+            if (v[k] != kSelf && v[k] >= kBack) pend |= 1u << k;
+        }
         for (int round = 0; round < 16; round++) {
-            bool changed = false;
-            uint32_t v[kPer], v2[kPer];
+            uint32_t v2[kPer];
+            // (all reads of a round are issued before the first dependent one is needed)
 #pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const uint32_t i = tid + k * kT;
-                v[k] = i < n ? ptr[i] : kSelf;
-            }
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const bool hop = v[k] != kSelf && v[k] >= kBack;
-                v2[k] = hop ? ptr[v[k] - kBack] : kSelf;
-            }
+            for (int k = 0; k < kPer; k++) v2[k] = (pend >> k) & 1 ? ptr[v[k] - kBack] : kSelf;
             WG_SYNC();   // every read of this round precedes its writes
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                if (v2[k] != kSelf) {
-                    ptr[tid + k * kT] = (uint16_t)v2[k];
-                    // a pointer that now leaves the step is final; only one that still
-                    // points into the step can need another round
-                    changed = changed || v2[k] >= kBack;
+                if ((pend >> k) & 1) {
+                    if (v2[k] != kSelf) {
+                        v[k] = v2[k];
+                        ptr[tid + k * kT] = (uint16_t)v2[k];
+                    }
+                    if (v2[k] == kSelf || v2[k] < kBack) pend &= ~(1u << k);
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!__syncthreads_or(changed)) break;
+            // one barrier publishes the new pointers and the waves' "still moving" flags
+            const uint32_t wave_moving = __ballot(pend != 0) != 0;
+            if ((tid & 63) == 0) L.scan_carry[4 + (tid >> 6)] = wave_moving;
+            WG_SYNC();
+            uint32_t moving = 0;
+#pragma unroll
+            for (int k = 0; k < kT / 64; k++) moving |= L.scan_carry[4 + k];
+            if (!moving) break;
         }
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
         // bytes that have left the ring (read back from the output)
         {
-            uint32_t v[kPer];
             uint8_t byte[kPer];
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const uint32_t i = tid + k * kT;
-                v[k] = i < n ? ptr[i] : kSelf;
-            }
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
                 byte[k] = 0;
