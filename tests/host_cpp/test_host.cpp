@@ -1,0 +1,276 @@
+// GPU test of the C++ host classes (libdeflate-rsx_amd/host/rsx_deflate.hpp).  The cases
+// follow the reference's own tests for this surface (tests/batch_test.rs, the api.rs error
+// paths exercised by tests/security_limit.rs) and every result is checked against the CPU
+// oracle (oracle/rsx_oracle.h): what the GPU compresses must inflate to the input under
+// the oracle, what the oracle compresses must decode bit-exactly on the GPU.
+//
+// usage: test_host            run everything (needs a GPU)
+//        test_host --no-gpu   only the argument checks that never reach the engine
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rsx_deflate.hpp"
+#include "rsx_oracle.h"
+
+static int g_failed = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+            g_failed++;                                                              \
+        }                                                                            \
+    } while (0)
+
+using Buf = std::vector<uint8_t>;
+
+static Buf bytes_of(const char *s) { return Buf(s, s + std::strlen(s)); }
+
+// deterministic data: words from a small vocabulary (compressible) or xorshift bytes
+static Buf make_text(size_t n, uint64_t seed)
+{
+    static const char *words[] = {"the", "batch", "of", "streams", "window", "match", "literal", "huffman",
+                                  "block", "offset", "length", "engine", "and", "a", "gpu", "deflate"};
+    Buf out;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    while (out.size() < n) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        const char *w = words[(x >> 20) & 15];
+        out.insert(out.end(), w, w + std::strlen(w));
+        out.push_back((x & 0xF00) ? ' ' : '\n');
+    }
+    out.resize(n);
+    return out;
+}
+static Buf make_noise(size_t n, uint64_t seed)
+{
+    Buf out(n);
+    uint64_t x = seed * 0xD1342543DE82EF95ull + 7;
+    for (size_t i = 0; i < n; i++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        out[i] = (uint8_t)(x >> 32);
+    }
+    return out;
+}
+
+static Buf oracle_compress(const Buf &in, int level, int fmt)
+{
+    orc_compressor *c = orc_compressor_new(level);
+    Buf out(orc_compress_bound(fmt, in.size()));
+    size_t n = 0;
+    const int r = orc_compress(c, fmt, in.data(), in.size(), out.data(), out.size(), &n);
+    orc_compressor_free(c);
+    CHECK(r == 0);
+    out.resize(n);
+    return out;
+}
+static bool oracle_inflates_to(const Buf &stream, const Buf &want, int fmt)
+{
+    Buf out(want.size() + 1);
+    size_t used = 0, produced = 0;
+    const int r = orc_decompress(fmt, stream.data(), stream.size(), out.data(), want.size(), &used, &produced);
+    return r == 0 && produced == want.size() && std::memcmp(out.data(), want.data(), want.size()) == 0;
+}
+
+static std::vector<rsx::Bytes> refs(const std::vector<Buf> &v)
+{
+    std::vector<rsx::Bytes> r;
+    for (const Buf &b : v) r.emplace_back(b);
+    return r;
+}
+
+static void test_argument_errors()
+{
+    // src/api.rs:11-16
+    for (int level : {-1, 13, 100}) {
+        try {
+            rsx::Compressor c(level);
+            CHECK(!"level accepted");
+        } catch (const rsx::Error &e) {
+            CHECK(e.kind() == rsx::ErrorKind::InvalidInput);
+            CHECK(std::string(e.what()) == "Compression level must be between 0 and 12");
+        }
+    }
+    // the guards run before anything touches the engine (src/api.rs:213-239)
+    rsx::Decompressor d;
+    Buf tiny(10);
+    try {
+        d.decompress_deflate(tiny, 10 * 2000 + 4096 + 1);
+        CHECK(!"ratio guard");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::InvalidInput);
+        CHECK(std::string(e.what()) == "Expected size 24097 exceeds safety limit for input size 10");
+    }
+    d.set_max_memory_limit(1000);
+    try {
+        d.decompress_zlib(tiny, 1001);
+        CHECK(!"memory guard");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::InvalidInput);
+        CHECK(std::string(e.what()) == "Expected size 1001 exceeds maximum memory limit 1000");
+    }
+    // overlap check of the _into forms (src/api.rs:114-119, :277-282, :303-315)
+    Buf both(64);
+    rsx::Compressor c(6);
+    try {
+        c.compress_deflate_into(rsx::Bytes(both.data(), 32), rsx::BytesMut(both.data() + 16, 48));
+        CHECK(!"overlap");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::InvalidInput);
+        CHECK(std::string(e.what()) == "Input and output buffers overlap");
+    }
+    rsx::Decompressor d2;
+    try {
+        d2.decompress_gzip_into(rsx::Bytes(both.data(), 32), rsx::BytesMut(both.data() + 31, 8));
+        CHECK(!"overlap");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::InvalidInput);
+    }
+    CHECK(c.deflate_compress_bound(1000) == orc_compress_bound(ORC_FMT_DEFLATE, 1000));
+    CHECK(c.zlib_compress_bound(0) == orc_compress_bound(ORC_FMT_ZLIB, 0));
+    CHECK(c.gzip_compress_bound(123456789) == orc_compress_bound(ORC_FMT_GZIP, 123456789));
+}
+
+static void test_batch_roundtrip()
+{
+    std::vector<Buf> inputs = {bytes_of("Hello world! This is a test string for deflate compression."),
+                               bytes_of("Another test string."),
+                               bytes_of("Repeating pattern repeating pattern repeating pattern repeating pattern."),
+                               bytes_of("Short"),
+                               Buf(1000, 0),
+                               make_text(300000, 3),
+                               make_noise(70000, 4),
+                               Buf()};
+    for (size_t level : {1, 6, 9, 12}) {
+        rsx::BatchCompressor bc(level);
+        auto comp = bc.compress_batch(refs(inputs));
+        CHECK(comp.size() == inputs.size());
+        std::vector<size_t> caps;
+        for (size_t i = 0; i < inputs.size(); i++) {
+            CHECK(!comp[i].empty());   // even "" has a stream (tests/batch_test.rs:57)
+            CHECK(oracle_inflates_to(comp[i], inputs[i], ORC_FMT_DEFLATE));
+            caps.push_back(inputs[i].size());
+        }
+        rsx::BatchDecompressor bd;
+        auto back = bd.decompress_batch(refs(comp), caps);
+        CHECK(back.size() == inputs.size());
+        for (size_t i = 0; i < inputs.size(); i++) CHECK(back[i].has_value() && *back[i] == inputs[i]);
+    }
+    // empty batches (tests/batch_test.rs:43-52)
+    CHECK(rsx::BatchCompressor(6).compress_batch({}).empty());
+    CHECK(rsx::BatchDecompressor().decompress_batch({}, {}).empty());
+}
+
+static void test_batch_decode_oracle_streams()
+{
+    std::vector<Buf> texts = {make_text(1 << 20, 11), make_text(65536, 12), make_noise(65536, 13), Buf(40000, 'a'),
+                              bytes_of("x")};
+    for (int fmt : {ORC_FMT_DEFLATE, ORC_FMT_ZLIB, ORC_FMT_GZIP}) {
+        std::vector<Buf> streams;
+        std::vector<size_t> caps;
+        for (size_t i = 0; i < texts.size(); i++) {
+            const Buf &t = texts[i];
+            // the reference has no stored-block fallback above level 0 (src/compress/mod.rs:775),
+            // so incompressible bytes overflow its bound: those go in as stored blocks
+            streams.push_back(oracle_compress(t, i == 2 ? 0 : 6, fmt));
+            caps.push_back(t.size() + 100);   // an upper bound, not the exact size
+        }
+        rsx::BatchDecompressor bd(nullptr, (rsx::Format)fmt);
+        auto got = bd.decompress_batch(refs(streams), caps);
+        for (size_t i = 0; i < texts.size(); i++) CHECK(got[i].has_value() && *got[i] == texts[i]);
+    }
+}
+
+static void test_batch_failures()
+{
+    // garbage and a too-small slot give None for that item only (tests/batch_test.rs:78-110)
+    Buf good_text = bytes_of("Hello world!");
+    Buf good = oracle_compress(good_text, 6, ORC_FMT_DEFLATE);
+    Buf invalid = {0, 1, 2, 3, 4, 5};
+    Buf cut(good.begin(), good.begin() + good.size() / 2);
+    rsx::BatchDecompressor bd;
+    auto got = bd.decompress_batch({rsx::Bytes(invalid), rsx::Bytes(good), rsx::Bytes(good), rsx::Bytes(cut)},
+                                   {100, good_text.size() - 1, good_text.size(), 100});
+    CHECK(got.size() == 4);
+    CHECK(!got[0].has_value());
+    CHECK(!got[1].has_value());
+    CHECK(got[2].has_value() && *got[2] == good_text);
+    CHECK(!got[3].has_value());
+}
+
+static void test_one_shot_api()
+{
+    Buf text = make_text(200000, 21);
+    rsx::Compressor c(6);
+    rsx::Decompressor d;
+    Buf z = c.compress_zlib(text), g = c.compress_gzip(text), r = c.compress_deflate(text);
+    CHECK(oracle_inflates_to(z, text, ORC_FMT_ZLIB));
+    CHECK(oracle_inflates_to(g, text, ORC_FMT_GZIP));
+    CHECK(oracle_inflates_to(r, text, ORC_FMT_DEFLATE));
+    CHECK(d.decompress_zlib(z, text.size()) == text);
+    CHECK(d.decompress_gzip(g, text.size()) == text);
+    CHECK(d.decompress_deflate(r, text.size()) == text);
+    // _into forms: exact fit, then one byte short
+    Buf out(c.gzip_compress_bound(text.size()));
+    const size_t n = c.compress_gzip_into(text, out);
+    CHECK(n == g.size() && std::memcmp(out.data(), g.data(), n) == 0);
+    Buf small(g.size() - 1);
+    try {
+        c.compress_gzip_into(text, small);
+        CHECK(!"fits?");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::Other && std::string(e.what()) == "Compression failed");
+    }
+    try {
+        c.compress_deflate_into(text, rsx::BytesMut(small.data(), 10));
+        CHECK(!"fits?");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::Other && std::string(e.what()) == "Insufficient space");
+    }
+    Buf back(text.size());
+    CHECK(d.decompress_gzip_into(g, back) == text.size() && back == text);
+    // a corrupted trailer is InvalidData (src/api.rs:258-261)
+    Buf bad = z;
+    bad[bad.size() - 1] ^= 1;
+    try {
+        d.decompress_zlib(bad, text.size());
+        CHECK(!"accepted");
+    } catch (const rsx::Error &e) {
+        CHECK(e.kind() == rsx::ErrorKind::InvalidData && std::string(e.what()) == "Decompression failed");
+    }
+    // checksums against the oracle, chained in two pieces
+    const uint32_t c1 = rsx::crc32(0, rsx::Bytes(text.data(), 1000));
+    CHECK(rsx::crc32(c1, rsx::Bytes(text.data() + 1000, text.size() - 1000)) == orc_crc32(0, text.data(), text.size()));
+    const uint32_t a1 = rsx::adler32(1, rsx::Bytes(text.data(), 77777));
+    CHECK(rsx::adler32(a1, rsx::Bytes(text.data() + 77777, text.size() - 77777)) ==
+          orc_adler32(1, text.data(), text.size()));
+    CHECK(rsx::crc32(0, Buf()) == 0 && rsx::adler32(1, Buf()) == 1);
+}
+
+int main(int argc, char **argv)
+{
+    const bool no_gpu = argc > 1 && std::strcmp(argv[1], "--no-gpu") == 0;
+    test_argument_errors();
+    if (!no_gpu) {
+        try {
+            test_batch_roundtrip();
+            test_batch_decode_oracle_streams();
+            test_batch_failures();
+            test_one_shot_api();
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "FAILED: unexpected exception: %s\n", e.what());
+            g_failed++;
+        }
+    }
+    if (g_failed) {
+        std::fprintf(stderr, "%d check(s) failed\n", g_failed);
+        return 1;
+    }
+    std::printf("host c++ tests ok%s\n", no_gpu ? " (argument checks only)" : "");
+    return 0;
+}
