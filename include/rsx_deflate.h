@@ -55,6 +55,11 @@ extern "C" {
  * 0 Success, 1 InsufficientSpace */
 #define RSX_COMPRESS_INSUFFICIENT_SPACE 1
 
+/* FlushMode of the raw compressor, src/compress/mod.rs:424-429 (None is not offered: a
+ * batch call always ends on a byte boundary) */
+#define RSX_FLUSH_SYNC 1   /* end with an empty stored block; the DEFLATE stream stays open */
+#define RSX_FLUSH_FINISH 2 /* end with the final block */
+
 /* checksum kinds for rsx_batch_checksum* */
 #define RSX_CHECKSUM_CRC32 0   /* src/crc32/mod.rs:332-365 */
 #define RSX_CHECKSUM_ADLER32 1 /* src/adler32/mod.rs:115-152 */
@@ -94,6 +99,19 @@ uint64_t rsx_compress_bound(int format, uint64_t len);
 int rsx_batch_compress(rsx_engine *e, int format, int level, const uint8_t *in,
                        const uint64_t *in_off, size_t n, uint8_t *out, const uint64_t *out_off,
                        uint64_t *out_sizes, int32_t *status);
+
+/*
+ * The encoder step of the streaming adapter, DeflateEncoder::flush_buffer
+ * (src/stream.rs:42-199): raw DEFLATE of every item in 256 KiB chunks like
+ * rsx_batch_compress, but with flush = RSX_FLUSH_SYNC no chunk carries the
+ * final-block bit and every chunk ends with an empty stored block, so the
+ * outputs of successive calls concatenate into one DEFLATE stream; the last
+ * call uses RSX_FLUSH_FINISH (= rsx_batch_compress, format raw).  Give a slot
+ * rsx_compress_bound(RSX_FORMAT_DEFLATE, len) + 5 bytes (src/stream.rs:107-109).
+ */
+int rsx_batch_compress_flush(rsx_engine *e, int level, int flush, const uint8_t *in,
+                             const uint64_t *in_off, size_t n, uint8_t *out, const uint64_t *out_off,
+                             uint64_t *out_sizes, int32_t *status);
 
 /*
  * GPU counterpart of BatchDecompressor::decompress_batch (src/batch.rs:74-101;

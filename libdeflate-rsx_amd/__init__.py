@@ -12,7 +12,7 @@ raises if the shared library or a GPU is missing.
 """
 from .engine import (Engine, RsxError, FORMAT_DEFLATE, FORMAT_ZLIB, FORMAT_GZIP, SUCCESS,
                      BAD_DATA, SHORT_OUTPUT, INSUFFICIENT_SPACE, SHORT_INPUT, CHECKSUM_CRC32,
-                     CHECKSUM_ADLER32, compress_bound, default_engine, library_path, load_library)
+                     CHECKSUM_ADLER32, FLUSH_SYNC, FLUSH_FINISH, compress_bound, default_engine, library_path, load_library)
 from .batch import BatchCompressor, BatchDecompressor
 from .api import Compressor, Decompressor, crc32, adler32
 
@@ -20,5 +20,5 @@ __all__ = [
     "Engine", "RsxError", "BatchCompressor", "BatchDecompressor", "Compressor", "Decompressor",
     "crc32", "adler32", "compress_bound", "default_engine", "library_path", "load_library",
     "FORMAT_DEFLATE", "FORMAT_ZLIB", "FORMAT_GZIP", "SUCCESS", "BAD_DATA", "SHORT_OUTPUT",
-    "INSUFFICIENT_SPACE", "SHORT_INPUT", "CHECKSUM_CRC32", "CHECKSUM_ADLER32",
+    "INSUFFICIENT_SPACE", "SHORT_INPUT", "CHECKSUM_CRC32", "CHECKSUM_ADLER32", "FLUSH_SYNC", "FLUSH_FINISH",
 ]

@@ -210,7 +210,7 @@ int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_
     int r = ws_reserve(e, deflate_ws_bytes(n, total_in, max_item, level));
     if (r != RSX_OK) return r;
     return deflate_launch(e, format, level, in, in_off, n, total_in, max_item, out, out_off,
-                          out_sizes, status);
+                          out_sizes, status, RSX_FLUSH_FINISH);
 }
 
 // ---- host-pointer entry points ------------------------------------------------
@@ -285,7 +285,7 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
 
     if (op == 0)
         r = deflate_launch(e, format, level, s.d_in, s.d_in_off, n, si.total, si.max_item, s.d_out,
-                           s.d_out_off, s.d_sizes, s.d_status);
+                           s.d_out_off, s.d_sizes, s.d_status, kind /* compress: the flush mode */);
     else if (op == 1)
         r = inflate_launch(e, format, s.d_in, s.d_in_off, n, si.total, so.total, so.max_item,
                            s.d_out, s.d_out_off, s.d_sizes, s.d_status);
@@ -330,8 +330,21 @@ int rsx_batch_compress(rsx_engine *e, int format, int level, const uint8_t *in,
     if (level < 0 || level > 12) return bad(e, "Compression level must be between 0 and 12");
     if (n == 0) return RSX_OK;
     if (!in_off || !out || !out_off || !out_sizes || !status) return bad(e, "null pointer");
-    return stage_and_run(e, 0, format, level, 0, 0, in, in_off, n, out, out_off, out_sizes, status,
-                         nullptr);
+    return stage_and_run(e, 0, format, level, RSX_FLUSH_FINISH, 0, in, in_off, n, out, out_off, out_sizes,
+                         status, nullptr);
+}
+
+int rsx_batch_compress_flush(rsx_engine *e, int level, int flush, const uint8_t *in,
+                             const uint64_t *in_off, size_t n, uint8_t *out, const uint64_t *out_off,
+                             uint64_t *out_sizes, int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (flush != RSX_FLUSH_SYNC && flush != RSX_FLUSH_FINISH) return bad(e, "bad flush mode");
+    if (level < 0 || level > 12) return bad(e, "Compression level must be between 0 and 12");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    return stage_and_run(e, 0, RSX_FORMAT_DEFLATE, level, flush, 0, in, in_off, n, out, out_off, out_sizes,
+                         status, nullptr);
 }
 
 int rsx_batch_decompress(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off,

@@ -1173,7 +1173,8 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
     uint8_t *__restrict__ scratch, uint64_t scratch_stride, uint32_t *__restrict__ tokbuf,
-    uint32_t *__restrict__ chunk_size, uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf)
+    uint32_t *__restrict__ chunk_size, uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf,
+    int finish)
 {
     __shared__ ChunkLds L;
     uint32_t *mp = pairbuf ? pairbuf + (size_t)blockIdx.x * kChunk * kPairs : nullptr;
@@ -1190,7 +1191,8 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
         const uint64_t ib = in_off[item], len = in_off[item + 1] - ib;
         const uint64_t cb = (uint64_t)k * kChunk;
         const uint32_t clen = (uint32_t)(len - cb < kChunk ? len - cb : kChunk);
-        const bool last = cb + clen >= len;
+        // FlushMode::Sync leaves the item's stream open: every chunk ends byte aligned, none is final
+        const bool last = finish && cb + clen >= len;
         uint32_t *outw = reinterpret_cast<uint32_t *>(scratch + (size_t)ch * scratch_stride);
         uint32_t sz;
         sz = compress_chunk(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
@@ -1205,7 +1207,8 @@ __global__ __launch_bounds__(256) void deflate_gather_kernel(
     const uint32_t *__restrict__ chunk_first, const uint8_t *__restrict__ scratch,
     uint64_t scratch_stride, const uint32_t *__restrict__ chunk_size,
     const uint32_t *__restrict__ sums, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
-    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status)
+    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, const uint8_t *__restrict__ in,
+    int finish)
 {
     const uint32_t item = blockIdx.x;
     if (item >= n) return;
@@ -1216,7 +1219,15 @@ __global__ __launch_bounds__(256) void deflate_gather_kernel(
     const uint32_t trl = format == RSX_FORMAT_ZLIB ? 4 : format == RSX_FORMAT_GZIP ? 8 : 0;
     uint64_t total = hdr + trl;
     for (uint32_t c = c0; c < c1; c++) total += chunk_size[c];
-    if (total > slot) {
+    // The whole item as stored blocks of 65535 bytes (the level-0 format,
+    // src/compress/mod.rs:1400-1464) when that is smaller: incompressible items then fit the
+    // compress bound however many chunks they have (a chunk of stored blocks pays for a short
+    // fifth block and its sync flush).  An open stream still ends with the empty stored block.
+    const uint64_t ilen = in_off[item + 1] - in_off[item];
+    const uint64_t nblk = ilen ? (ilen + 65534) / 65535 : 1;
+    const uint64_t stored_total = hdr + trl + ilen + 5 * nblk + (finish ? 0 : 5);
+    const bool stored = stored_total <= slot && (total > slot || stored_total < total);
+    if (total > slot && !stored) {
         // CompressResult::InsufficientSpace (src/compress/mod.rs:756-758)
         if (threadIdx.x == 0) {
             status[item] = RSX_COMPRESS_INSUFFICIENT_SPACE;
@@ -1225,14 +1236,38 @@ __global__ __launch_bounds__(256) void deflate_gather_kernel(
         return;
     }
     uint64_t at = hdr;
-    for (uint32_t c = c0; c < c1; c++) {
-        const uint8_t *s = scratch + (size_t)c * scratch_stride;
-        const uint32_t sz = chunk_size[c];
-        for (uint32_t k = threadIdx.x; k < sz; k += blockDim.x) o[at + k] = s[k];
-        at += sz;
+    if (stored) {
+        const uint8_t *src = in + in_off[item];
+        for (uint64_t b = 0; b < nblk; b++) {
+            const uint64_t pos = b * 65535;
+            const uint32_t blen = (uint32_t)(ilen - pos < 65535 ? ilen - pos : 65535);
+            uint8_t *q = o + at;
+            if (threadIdx.x == 0) {
+                q[0] = (finish && b == nblk - 1) ? 1 : 0;
+                q[1] = (uint8_t)blen;
+                q[2] = (uint8_t)(blen >> 8);
+                q[3] = (uint8_t)~blen;
+                q[4] = (uint8_t)(~blen >> 8);
+            }
+            for (uint32_t k = threadIdx.x; k < blen; k += blockDim.x) q[5 + k] = src[pos + k];
+            at += 5 + blen;
+        }
+        if (!finish) {
+            if (threadIdx.x == 0) {
+                o[at] = 0; o[at + 1] = 0; o[at + 2] = 0; o[at + 3] = 0xFF; o[at + 4] = 0xFF;
+            }
+            at += 5;
+        }
+        total = stored_total;
+    } else {
+        for (uint32_t c = c0; c < c1; c++) {
+            const uint8_t *s = scratch + (size_t)c * scratch_stride;
+            const uint32_t sz = chunk_size[c];
+            for (uint32_t k = threadIdx.x; k < sz; k += blockDim.x) o[at + k] = s[k];
+            at += sz;
+        }
     }
     if (threadIdx.x == 0) {
-        const uint64_t ilen = in_off[item + 1] - in_off[item];
         if (format == RSX_FORMAT_ZLIB) {
             // src/compress/mod.rs:2257-2269, :2288-2296
             uint32_t h = (8u << 8) | (7u << 12);
@@ -1286,7 +1321,7 @@ size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int leve
 
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
                    size_t n, uint64_t total_in, uint64_t max_item, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status)
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, int flush)
 {
     if (n == 0) return RSX_OK;
     if (n > 0x7FFFFFFFull || max_item >= (1ull << 32)) {
@@ -1325,7 +1360,8 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     (void)hipEventRecord(e->ev_begin, e->stream);
     deflate_chunks_kernel<<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
                                                        (uint32_t)chunks, lp, scratch, stride, tokbuf,
-                                                       chunk_size, pairbuf, costbuf);
+                                                       chunk_size, pairbuf, costbuf,
+                                                       flush == RSX_FLUSH_FINISH);
     (void)hipEventRecord(e->ev_end, e->stream);
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
@@ -1347,7 +1383,8 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     }
     deflate_gather_kernel<<<(uint32_t)n, 256, 0, e->stream>>>(format, level, in_off, (uint32_t)n,
                                                               chunk_first, scratch, stride, chunk_size,
-                                                              sums, out, out_off, out_sizes, status);
+                                                              sums, out, out_off, out_sizes, status, in,
+                                                              flush == RSX_FLUSH_FINISH);
     RSX_HIP(e, hipGetLastError());
     return RSX_OK;
 }

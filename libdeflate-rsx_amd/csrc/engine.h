@@ -75,4 +75,4 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
 size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int level);
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
                    size_t n, uint64_t total_in, uint64_t max_item, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status);
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, int flush);

@@ -8,6 +8,7 @@ import numpy as np
 FORMAT_DEFLATE, FORMAT_ZLIB, FORMAT_GZIP = 0, 1, 2
 SUCCESS, BAD_DATA, SHORT_OUTPUT, INSUFFICIENT_SPACE, SHORT_INPUT = range(5)
 CHECKSUM_CRC32, CHECKSUM_ADLER32 = 0, 1
+FLUSH_SYNC, FLUSH_FINISH = 1, 2   # FlushMode, src/compress/mod.rs:424-429
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -24,6 +25,7 @@ SYMBOLS = [
     ("rsx_engine_last_kernel_ms", C.c_float, [_P]),
     ("rsx_compress_bound", C.c_uint64, [C.c_int, C.c_uint64]),
     ("rsx_batch_compress", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    ("rsx_batch_compress_flush", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_decompress", C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_checksum", C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, C.c_size_t, _P]),
     ("rsx_crc32", C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -132,6 +134,24 @@ class Engine:
         self._check(self._lib.rsx_batch_compress(self._h, fmt, level, _np_ptr(flat), in_off.ctypes.data,
                                                  n, out.ctypes.data, out_off.ctypes.data,
                                                  sizes.ctypes.data, status.ctypes.data))
+        res = [out[int(out_off[i]):int(out_off[i]) + int(sizes[i])].tobytes() if status[i] == 0 else None
+               for i in range(n)]
+        return res, status[:n]
+
+    def batch_compress_flush(self, items, level=6, flush=FLUSH_SYNC):
+        """raw DEFLATE pieces for a streaming encoder (src/stream.rs:42-199): with FLUSH_SYNC the
+        pieces of successive calls concatenate into one stream -> (list of bytes-or-None, status)"""
+        n = len(items)
+        flat, in_off = self._flatten(items)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.asarray([compress_bound(FORMAT_DEFLATE, len(x)) + 5 for x in items], dtype=np.uint64),
+                  out=out_off[1:])
+        out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+        sizes = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        self._check(self._lib.rsx_batch_compress_flush(self._h, level, flush, _np_ptr(flat), in_off.ctypes.data,
+                                                       n, out.ctypes.data, out_off.ctypes.data,
+                                                       sizes.ctypes.data, status.ctypes.data))
         res = [out[int(out_off[i]):int(out_off[i]) + int(sizes[i])].tobytes() if status[i] == 0 else None
                for i in range(n)]
         return res, status[:n]

@@ -5,6 +5,7 @@
 //
 //   rsx::BatchCompressor / rsx::BatchDecompressor   src/batch.rs:5-58, :60-101
 //   rsx::Compressor / rsx::Decompressor             src/api.rs:5-133, :135-301
+//   rsx::DeflateEncoder                             src/stream.rs:15-233
 //   rsx::crc32 / rsx::adler32                       src/lib.rs:15-17
 //
 // Same names, argument meaning and error behaviour.  io::Error becomes rsx::Error with the
@@ -367,6 +368,83 @@ class Decompressor {
     size_t max_memory_limit_ = std::numeric_limits<size_t>::max();
     size_t limit_ratio_ = 2000;
     std::shared_ptr<Engine> engine_;
+};
+
+// src/stream.rs:15-233: buffers what is written and compresses the buffer in 256 KiB
+// chunks whenever it reaches buffer_size (1 MiB unless changed), on flush() and on
+// finish().  All pieces but the last end with a sync flush, so what reaches the writer is
+// one raw DEFLATE stream.  Writer is anything callable as writer(const uint8_t *, size_t).
+// finish() must be called to end the stream; the destructor tries and swallows errors,
+// like the reference's Drop (src/stream.rs:227-233).
+template <class Writer>
+class DeflateEncoder {
+  public:
+    DeflateEncoder(Writer writer, size_t level, std::shared_ptr<Engine> engine = nullptr)
+        : writer_(std::move(writer)), level_(level), engine_(std::move(engine))
+    {
+        buffer_.reserve(buffer_size_);
+    }
+    DeflateEncoder(const DeflateEncoder &) = delete;
+    DeflateEncoder &operator=(const DeflateEncoder &) = delete;
+    ~DeflateEncoder()
+    {
+        if (!finished_) {
+            try {
+                flush_buffer(true);
+            } catch (...) {
+            }
+        }
+    }
+
+    DeflateEncoder &with_buffer_size(size_t size)
+    {
+        buffer_size_ = size;
+        buffer_.reserve(size);
+        return *this;
+    }
+    // io::Write::write: takes everything, compresses when the buffer is full
+    size_t write(Bytes buf)
+    {
+        buffer_.insert(buffer_.end(), buf.data, buf.data + buf.size);
+        if (buffer_.size() >= buffer_size_) flush_buffer(false);
+        return buf.size;
+    }
+    // io::Write::flush: everything written so far becomes decodable
+    void flush() { flush_buffer(false); }
+    // ends the stream and hands the writer back
+    Writer finish()
+    {
+        flush_buffer(true);
+        return std::move(writer_);
+    }
+
+  private:
+    void flush_buffer(bool final_block)  // src/stream.rs:42-199
+    {
+        if (finished_) return;
+        if (buffer_.empty() && !final_block) return;
+        if (!engine_) engine_ = Engine::shared();
+        const uint64_t cap = rsx_compress_bound(RSX_FORMAT_DEFLATE, buffer_.size()) + 5;
+        out_.resize(cap);
+        const uint64_t in_off[2] = {0, buffer_.size()}, out_off[2] = {0, cap};
+        const uint8_t dummy = 0;
+        uint64_t size = 0;
+        int32_t status = 0;
+        engine_->check(rsx_batch_compress_flush(engine_->handle(), (int)level_,
+                                                final_block ? RSX_FLUSH_FINISH : RSX_FLUSH_SYNC,
+                                                buffer_.empty() ? &dummy : buffer_.data(), in_off, 1, out_.data(),
+                                                out_off, &size, &status));
+        if (status != RSX_SUCCESS || size > cap) throw Error(ErrorKind::Other, "Compression failed");
+        writer_(out_.data(), (size_t)size);
+        buffer_.clear();
+        if (final_block) finished_ = true;
+    }
+    Writer writer_;
+    size_t level_;
+    std::shared_ptr<Engine> engine_;
+    std::vector<uint8_t> buffer_, out_;
+    size_t buffer_size_ = 1024 * 1024;
+    bool finished_ = false;
 };
 
 // crate-level checksums (src/lib.rs:15-17): pass the previous result to continue one

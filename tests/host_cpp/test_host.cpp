@@ -6,6 +6,7 @@
 //
 // usage: test_host            run everything (needs a GPU)
 //        test_host --no-gpu   only the argument checks that never reach the engine
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -252,6 +253,64 @@ static void test_one_shot_api()
     CHECK(rsx::crc32(0, Buf()) == 0 && rsx::adler32(1, Buf()) == 1);
 }
 
+// src/stream.rs: what the encoder writes is one raw DEFLATE stream, whatever the write and
+// flush pattern; the oracle must inflate it to everything that was written
+static void test_stream_encoder()
+{
+    Buf text = make_text(3 * 1024 * 1024 + 12345, 31);
+    Buf noise = make_noise(300000, 32);
+    for (size_t level : {1, 6}) {
+        Buf sink;
+        auto writer = [&sink](const uint8_t *p, size_t n) { sink.insert(sink.end(), p, p + n); };
+        Buf all;
+        {
+            rsx::DeflateEncoder<decltype(writer)> enc(writer, level);
+            size_t at = 0, step = 1;
+            while (at < text.size()) {   // ragged writes, from 1 byte to ~700 KB
+                const size_t n = std::min(step, text.size() - at);
+                CHECK(enc.write(rsx::Bytes(text.data() + at, n)) == n);
+                all.insert(all.end(), text.begin() + at, text.begin() + at + n);
+                at += n;
+                step = step * 7 + 3;
+                if (step > 700000) step = 11;
+            }
+            enc.flush();
+            const size_t after_flush = sink.size();
+            enc.flush();                       // nothing buffered: writes nothing (src/stream.rs:43-45)
+            CHECK(sink.size() == after_flush);
+            enc.write(noise);                  // incompressible piece in the middle of the stream
+            all.insert(all.end(), noise.begin(), noise.end());
+            enc.write(bytes_of("tail"));
+            const Buf tail = bytes_of("tail");
+            all.insert(all.end(), tail.begin(), tail.end());
+            enc.finish();
+        }
+        CHECK(oracle_inflates_to(sink, all, ORC_FMT_DEFLATE));
+        // and the GPU decodes its own stream
+        rsx::Decompressor d;
+        CHECK(d.decompress_deflate(sink, all.size()) == all);
+    }
+    // an encoder that is dropped still ends its stream; an empty one is a valid empty stream
+    Buf sink;
+    auto writer = [&sink](const uint8_t *p, size_t n) { sink.insert(sink.end(), p, p + n); };
+    {
+        rsx::DeflateEncoder<decltype(writer)> enc(writer, 6);
+        enc.with_buffer_size(1000).write(make_text(2500, 5));
+    }
+    CHECK(oracle_inflates_to(sink, make_text(2500, 5), ORC_FMT_DEFLATE));
+    sink.clear();
+    {
+        rsx::DeflateEncoder<decltype(writer)> enc(writer, 6);
+        enc.finish();
+    }
+    CHECK(!sink.empty() && oracle_inflates_to(sink, Buf(), ORC_FMT_DEFLATE));
+    // a slot of exactly the bound holds incompressible input of several chunks
+    Buf big = make_noise(1 << 20, 33);
+    rsx::Compressor c(6);
+    Buf z = c.compress_deflate(big);
+    CHECK(oracle_inflates_to(z, big, ORC_FMT_DEFLATE));
+}
+
 int main(int argc, char **argv)
 {
     const bool no_gpu = argc > 1 && std::strcmp(argv[1], "--no-gpu") == 0;
@@ -262,6 +321,7 @@ int main(int argc, char **argv)
             test_batch_decode_oracle_streams();
             test_batch_failures();
             test_one_shot_api();
+            test_stream_encoder();
         } catch (const std::exception &e) {
             std::fprintf(stderr, "FAILED: unexpected exception: %s\n", e.what());
             g_failed++;

@@ -146,3 +146,26 @@ def test_api_surface(rsx):
     with pytest.raises(RuntimeError, match="Decompression failed"):
         rsx.Decompressor().decompress_deflate(b"\x00\x01\x02\x03\x04\x05", 100)
     assert c.deflate_compress_bound(65536) == 65556 and c.gzip_compress_bound(0) == 33
+
+
+def test_sync_flushed_pieces_concatenate(rsx, eng):
+    """rsx_batch_compress_flush (the encoder step of src/stream.rs:42-199): pieces compressed with
+    FLUSH_SYNC in separate calls and a last piece with FLUSH_FINISH form one raw DEFLATE stream that
+    the oracle inflates to the concatenated input; a sync-flushed piece alone is not a finished stream."""
+    pieces = [corpus.text(700000, 41), corpus.mixed(300000, 42), b"", b"x", corpus.text(5000, 43)]
+    for level in (1, 6, 12):
+        out, st = eng.batch_compress_flush(pieces[:-1], level, rsx.FLUSH_SYNC)
+        assert list(st) == [0] * (len(pieces) - 1)
+        last, st = eng.batch_compress_flush(pieces[-1:], level, rsx.FLUSH_FINISH)
+        assert list(st) == [0]
+        stream = b"".join(out) + last[0]
+        want = b"".join(pieces)
+        assert o.decompress(stream, len(want)) == (o.SUCCESS, len(stream), want)
+        # every sync-flushed piece ends on a byte boundary with the empty stored block
+        for piece_out in out:
+            assert piece_out.endswith(b"\x00\x00\xff\xff")
+        r, _, _ = o.decompress(out[0], len(pieces[0]))
+        assert r != o.SUCCESS
+        # FLUSH_FINISH is the ordinary raw compress
+        same, _ = eng.batch_compress(pieces[-1:], rsx.FORMAT_DEFLATE, level)
+        assert same[0] == last[0]
