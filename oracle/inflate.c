@@ -7,8 +7,9 @@
  * header), :509-1072 (Huffman block body), :1324-1495 (decode-table build),
  * with the table geometry of src/decompress/tables.rs:3-8.
  *
- * Two defects of the reference are deliberately NOT restated, because they
- * corrupt well-formed streams instead of defining behaviour:
+ * Three defects of the reference are deliberately NOT restated, because they
+ * are unsigned underflows or corrupt well-formed streams instead of defining
+ * behaviour:
  *   - an end-of-block codeword longer than the litlen root table is not
  *     recognised after the subtable lookup (src/decompress/mod.rs:941-967 has
  *     no second END_OF_BLOCK test; src/decompress/x86.rs:2304-2309 consumes it
@@ -16,6 +17,12 @@
  *   - src/decompress/x86.rs:2208-2213 subtracts 3 from bitsleft without
  *     checking that 3 bits exist (empty input underflows).  Here, as in
  *     src/decompress/mod.rs:226-233, that is ShortInput.
+ *   - src/decompress/mod.rs:943-947 takes the bits of a root-table
+ *     end-of-block entry without checking that they exist: on a stream cut
+ *     where the zero padding of the bit buffer happens to spell the
+ *     end-of-block code (all zeros in the static code) `bitsleft` underflows
+ *     (a panic in a debug build, Success on a truncated stream otherwise).
+ *     Here, as for every other symbol (:963-966), that is ShortInput.
  */
 #include "rsx_oracle.h"
 
@@ -343,8 +350,10 @@ static int huffman_block(inflater *d, bitreader *b, uint8_t *out, size_t out_len
         uint32_t e = d->litlen_table[b->bitbuf & litlen_mask];
         if (e & HUFFDEC_EXCEPTIONAL) {
             if (e & HUFFDEC_END_OF_BLOCK) {
-                TAKE(b, e & 0xFF);
                 *out_idx = o;
+                if (b->bitsleft < (e & 0xFF))
+                    return ORC_SHORT_INPUT;
+                TAKE(b, e & 0xFF);
                 return ORC_SUCCESS;
             }
             unsigned main_bits = e & 0xFF;

@@ -146,3 +146,38 @@ def test_gzip_header_fields(eng):
     with gzip.GzipFile(filename="name.txt", mode="wb", fileobj=buf, mtime=0) as f:
         f.write(t)
     check_against_oracle(eng, [buf.getvalue()], [len(t)], 2)
+
+
+@pytest.mark.parametrize("seed", [2024, 7, 99, 12345])
+def test_corrupted_streams_agree_with_oracle(eng, seed):
+    """Six hundred damaged streams per seed (bit flips, cuts, spliced tails, short slots) in all three
+    containers: the status code of every item, and the bytes of every item that still decodes, must be
+    the oracle's.  Damage lands in headers, code-length tables, token data and trailers alike."""
+    rs = np.random.RandomState(seed)
+    texts = [corpus.text(40000, 50), corpus.mixed(30000, 51), bytes(5000), corpus.text(300, 52),
+             rs.randint(0, 256, size=3000, dtype=np.uint8).tobytes()]
+    for fmt in (0, 1, 2):
+        good = []
+        for k, t in enumerate(texts):
+            level = 0 if k == 4 else (1, 6, 9)[k % 3]   # incompressible bytes go in as stored blocks
+            good.append((o.compress(t, level, fmt), len(t)))
+        streams, caps = [], []
+        for s, n in good:
+            for _ in range(40):
+                b = bytearray(s)
+                kind = rs.randint(0, 5)
+                if kind == 0:        # a few bit flips anywhere
+                    for _ in range(rs.randint(1, 4)):
+                        b[rs.randint(0, len(b))] ^= 1 << rs.randint(0, 8)
+                elif kind == 1:      # damage near the front: block header / code lengths
+                    b[rs.randint(0, min(len(b), 80))] ^= 1 << rs.randint(0, 8)
+                elif kind == 2:      # cut
+                    b = b[:rs.randint(0, len(b))]
+                elif kind == 3:      # overwrite the tail with noise
+                    at = rs.randint(0, len(b))
+                    b[at:] = rs.randint(0, 256, size=len(b) - at, dtype=np.uint8).tobytes()
+                else:                # intact stream, slot too small or larger than needed
+                    pass
+                streams.append(bytes(b))
+                caps.append(n if kind != 4 else int(rs.choice([0, n // 2, n - 1, n, n + 7])))
+        check_against_oracle(eng, streams, caps, fmt)
