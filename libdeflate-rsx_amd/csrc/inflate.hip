@@ -58,6 +58,10 @@ constexpr uint32_t kSubBits = 126;            // compressed bits per lane and ro
 // at least 2 bits), so a round that commits at least lane 0 always fits
 constexpr uint32_t kRoundOut = 16384 - 16;    // output bytes per round
 constexpr uint32_t kMaxMatches = 1536;        // match queue entries per round
+#ifndef RSX_WARM_BITS
+#define RSX_WARM_BITS 200
+#endif
+constexpr uint32_t kWarmBits = RSX_WARM_BITS;  // warm-up in front of a sub-sequence's first guess
 constexpr uint32_t kCopySub = 2048;           // output bytes resolved per copy step (u16 pointers fit in win)
 static_assert(kCopySub * 2 <= kWinBytes, "copy pointers live in the window buffer");
 static_assert(kSubBits / 2 * 258 <= kRoundOut && kSubBits / 2 <= kMaxMatches, "lane 0 must fit");
@@ -584,6 +588,26 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
     return r;
 }
 
+// A better first guess for a sub-sequence: start kWarmBits in front of it and take the
+// first token boundary at or behind `lo`.  Huffman streams re-synchronise, so after a
+// stretch of warm-up the decoder is often on real token boundaries already.
+__device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_t lo, int64_t end_b,
+                                      uint32_t litlen_mask)
+{
+    Decoder d;
+    d.init(L, from, litlen_mask);
+    const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
+    bool running = d.b < lo;
+    uint32_t guess = lo;
+    while (running) {
+        const StepOut o = decoder_step(L, d, litlen_mask);
+        const bool stop = d.b > end32 || o.kind == 3;   // nothing to learn from here on
+        guess = (!stop && d.tok == d.b && d.b >= lo) ? d.b : guess;
+        running = !stop && (d.tok != d.b || d.b < lo);
+    }
+    return guess;
+}
+
 // exclusive prefix sums of two 32-bit values over the workgroup
 __device__ inline void wg_exclusive_scan2(StreamLds &L, uint32_t a, uint32_t b, uint32_t *ea,
                                           uint32_t *eb)
@@ -636,8 +660,12 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     // sub-sequence i compares its start with where sub-sequence i-1 ended; the ones
     // that changed are compacted into a work list and re-decoded by the first lanes
     // of the workgroup, so late passes (few stragglers) occupy one wave, not all.
-    uint32_t start = lo;          // lane 0's guess is exact
     unsigned long long tq = RSX_DEV_TIMERS == 1 ? clock64() : 0;
+    // lane 0 starts where the previous round ended; the others warm up in front of their
+    // sub-sequence (a lane whose warm-up reaches back to b0 is exact as well)
+    uint32_t guess = lo;
+    if (tid > 0 && lo < bound) guess = warm_start(L, lo - b0 > kWarmBits ? lo - kWarmBits : b0, lo, end_b, litlen_mask);
+    uint32_t start = guess;
     Scan sc;
     if (start >= bound) {
         sc = Scan{start, 0, 0};   // nothing starts here (window exhausted)
@@ -652,7 +680,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     // the true prefix grows by at least one sub-sequence per pass, so kT passes suffice
     for (int pass = 0; pass <= kT; pass++) {
         WG_SYNC();
-        uint32_t ns = lo;
+        uint32_t ns = guess;
         if (tid > 0) {
             uint32_t pe = L.lane_exit[tid - 1];
             if (!(pe & (kExitEob | kExitStop))) ns = pe;
