@@ -829,7 +829,6 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     WG_SYNC();
     for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub) {
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
-        const uint32_t n = sub_end - sub_start;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
         static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
         reinterpret_cast<uint4 *>(ptr)[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -863,41 +862,42 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; }
         // Pointer jumping: a pointer into this step that lands on a non-literal byte takes
         // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
-        // registers; `pend` marks the ones that may still move.  A pointer is final once it
-        // leaves the step or lands on a literal.
+        // registers.  A pointer can still move while it points into the step (kBack <= v <
+        // kBack + kCopySub) and is not known to have landed on a literal; one that has is
+        // marked with kLanded (bit 16, above the 16 bits the table holds).  The rounds are
+        // branch-free: settled bytes read their own slot and rewrite their own value.
         constexpr int kPer = kCopySub / kT;
+        constexpr uint32_t kLanded = 0x10000;
         uint32_t v[kPer];
-        uint32_t pend = 0;
 #pragma unroll
-        for (int k = 0; k < kPer; k++) {
-            const uint32_t i = tid + k * kT;
-            v[k] = i < n ? ptr[i] : kSelf;
-            if (v[k] != kSelf && v[k] >= kBack) pend |= 1u << k;
-        }
+        for (int k = 0; k < kPer; k++) v[k] = ptr[tid + k * kT];   // slots behind n hold kSelf
         for (int round = 0; round < 16; round++) {
             uint32_t v2[kPer];
+            if (RSX_DEV_TIMERS && tid == 0) L.stat_copy++;
             // (all reads of a round are issued before the first dependent one is needed)
 #pragma unroll
-            for (int k = 0; k < kPer; k++) v2[k] = (pend >> k) & 1 ? ptr[v[k] - kBack] : kSelf;
+            for (int k = 0; k < kPer; k++) {
+                const uint32_t t = v[k] - kBack;
+                v2[k] = ptr[t < kCopySub ? t : (uint32_t)tid + k * kT];
+            }
             WG_SYNC();   // every read of this round precedes its writes
+            bool moving = false;
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                if ((pend >> k) & 1) {
-                    if (v2[k] != kSelf) {
-                        v[k] = v2[k];
-                        ptr[tid + k * kT] = (uint16_t)v2[k];
-                    }
-                    if (v2[k] == kSelf || v2[k] < kBack) pend &= ~(1u << k);
-                }
+                const bool pending = v[k] - kBack < kCopySub;
+                const uint32_t nv = v2[k] == kSelf ? v[k] | kLanded : v2[k];
+                v[k] = pending ? nv : v[k];
+                ptr[tid + k * kT] = (uint16_t)v[k];
+                moving = moving || v[k] - kBack < kCopySub;
             }
             // one barrier publishes the new pointers and the waves' "still moving" flags
-            const uint32_t wave_moving = __ballot(pend != 0) != 0;
+            const uint32_t wave_moving = __ballot(moving) != 0;
             if ((tid & 63) == 0) L.scan_carry[4 + (tid >> 6)] = wave_moving;
             WG_SYNC();
-            uint32_t moving = 0;
+            uint32_t any_moving = 0;
 #pragma unroll
-            for (int k = 0; k < kT / 64; k++) moving |= L.scan_carry[4 + k];
-            if (!moving) break;
+            for (int k = 0; k < kT / 64; k++) any_moving |= L.scan_carry[4 + k];
+            if (!any_moving) break;
         }
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
@@ -908,7 +908,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (int k = 0; k < kPer; k++) {
                 byte[k] = 0;
                 if (v[k] != kSelf) {
-                    const int64_t sp = (int64_t)sub_start - kBack + v[k];
+                    const int64_t sp = (int64_t)sub_start - kBack + (v[k] & 0xFFFF);
                     // two separate reads: written as one conditional expression the compiler
                     // folds them into a single FLAT load whose address is either in LDS or in
                     // global memory
