@@ -752,41 +752,33 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tq; tq = t; }
     // ---- emit -------------------------------------------------------------------------
     if (commit) {
-        uint32_t b = start;
-        uint64_t op = (uint64_t)round_start + ex_bytes;
+        // One exit test per step like the scan; literals and matches are told apart by
+        // selects and predicated stores, not branches.  Positions fit 32 bits (slots < 4 GiB).
+        uint32_t op = round_start + ex_bytes;
         uint32_t mi = ex_nm;
         int err = -1;
+        const uint32_t cap = (uint32_t)c.out_cap;
+        const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
         Decoder d;
-        d.init(L, b, litlen_mask);
-        while (d.tok != d.b || d.b < bound) {
+        d.init(L, start, litlen_mask);
+        bool running = d.b < bound;
+        while (running) {
             const StepOut o = decoder_step(L, d, litlen_mask);
-            if ((int64_t)d.b > end_b) {
-                err = RSX_SHORT_INPUT;
-                break;
-            }
-            if (o.kind == 1) {
-                if (op >= c.out_cap) {
-                    err = RSX_INSUFFICIENT_SPACE;
-                    break;
-                }
-                L.ring[((uint32_t)op + c.shift) & kRingMask] = (uint8_t)o.value;
-                op++;
-            } else if (o.kind == 2) {
-                if (o.value > op) {
-                    err = RSX_BAD_DATA;
-                    break;
-                }
-                if (op + o.len > c.out_cap) {
-                    err = RSX_INSUFFICIENT_SPACE;
-                    break;
-                }
-                L.mq.dl[mi] = (uint32_t)(op - round_start) | (o.len << 15);
+            const bool over = d.b > end32;
+            const bool lit = !over && o.kind == 1, mat = !over && o.kind == 2, eob = !over && o.kind == 3;
+            const bool no_room = (lit && op >= cap) || (mat && (op > cap || o.len > cap - op));
+            const bool too_far = mat && o.value > op;
+            const int e = over ? RSX_SHORT_INPUT : too_far ? RSX_BAD_DATA : no_room ? RSX_INSUFFICIENT_SPACE : -1;
+            const bool bad = e >= 0;
+            if (lit && !bad) L.ring[(op + c.shift) & kRingMask] = (uint8_t)o.value;
+            if (mat && !bad) {
+                L.mq.dl[mi] = (op - round_start) | (o.len << 15);
                 L.mq.dist[mi] = (uint16_t)(o.value - 1);
-                mi++;
-                op += o.len;
-            } else if (o.kind == 3) {
-                break;
             }
+            op += bad ? 0u : lit ? 1u : mat ? o.len : 0u;
+            mi += (mat && !bad) ? 1u : 0u;
+            err = bad ? e : err;
+            running = !bad && !eob && (d.tok != d.b || d.b < bound);
         }
         if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
     }
