@@ -128,6 +128,9 @@ struct HeaderScratch {
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
     uint8_t precode_lens[20];
+    uint32_t num_litlen, num_offset;   // alphabet sizes of the block whose tables are being built
+    uint32_t plan;                     // 0 nothing to build, 1 the static code, 2 lens[] of a dynamic header
+    uint32_t after;                    // window bit position behind the header
 };
 struct SpecScratch {
     uint32_t sub_start[kT];       // start handed to a sub-sequence that is re-decoded
@@ -273,6 +276,146 @@ __device__ __noinline__ bool build_decode_table(RSX_LDS uint32_t *table, const R
     }
 }
 
+// Orders the LDS traffic of one wave: its lanes run in step and the LDS serves a wave's
+// requests in order, so this only has to keep the compiler from moving accesses across.
+#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// The same table (src/decompress/mod.rs:1324-1495, entry for entry) built by the 64 lanes
+// of one wave.  Everything that decides the layout -- code-space checks, the canonical
+// first codeword of each length, the sizes and places of the subtables -- is computed
+// alike by every lane; the lanes share the counting, the sorting of the symbols, the
+// placing of the codewords of one length and the doubling of the table between lengths.
+__device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, const RSX_LDS uint8_t *lens,
+                                                     uint32_t num_syms, int kind, uint32_t table_bits,
+                                                     uint32_t max_codeword_len, RSX_LDS uint16_t *sorted_syms,
+                                                     RSX_LDS uint32_t *table_bits_ret,
+                                                     RSX_LDS uint32_t *len_counts, RSX_LDS uint32_t *offsets)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1;
+    if (lane < 16) len_counts[lane] = 0;
+    WAVE_SYNC();
+    for (uint32_t s = lane; s < num_syms; s += 64)
+        __hip_atomic_fetch_add(&len_counts[lens[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    WAVE_SYNC();
+    while (max_codeword_len > 1 && len_counts[max_codeword_len] == 0) max_codeword_len--;
+    if (table_bits_ret) {
+        if (table_bits > max_codeword_len) table_bits = max_codeword_len;
+        if (lane == 0) *table_bits_ret = table_bits;
+    }
+    // offsets[len] = where the symbols of that length start in sorted_syms
+    uint32_t codespace_used = 0;
+    {
+        uint32_t at = 0;
+        for (uint32_t len = 0; len <= max_codeword_len; len++) {
+            if (lane == 0) offsets[len] = at;
+            at += len_counts[len];
+            if (len >= 1) codespace_used = (codespace_used << 1) + len_counts[len];
+        }
+    }
+    WAVE_SYNC();
+    // stable counting sort, 64 symbols at a time: a lane's place is the running start of its
+    // length plus the number of lower lanes with the same length
+    for (uint32_t base = 0; base < num_syms; base += 64) {
+        const uint32_t s = base + lane;
+        const uint32_t mylen = s < num_syms ? lens[s] : 0xFFu;
+        for (uint32_t len = 0; len <= max_codeword_len; len++) {
+            const unsigned long long same = __ballot(mylen == len);
+            if (same) {   // (uniform)
+                const uint32_t o = offsets[len];
+                if (mylen == len) sorted_syms[o + (uint32_t)__popcll(same & below)] = (uint16_t)s;
+                if (lane == 0) offsets[len] = o + (uint32_t)__popcll(same);
+            }
+        }
+        WAVE_SYNC();
+    }
+    // now offsets[len] = end of the symbols of that length
+
+    if (codespace_used > (1u << max_codeword_len)) return false;
+    if (codespace_used < (1u << max_codeword_len)) {
+        uint32_t s;
+        if (codespace_used == 0) {
+            s = 0;
+        } else {
+            if (codespace_used != (1u << (max_codeword_len - 1)) || len_counts[1] != 1) return false;
+            s = sorted_syms[offsets[0]];
+        }
+        const uint32_t e = make_entry(kind, s, 1);
+        for (uint32_t i = lane; i < (1u << table_bits); i += 64) table[i] = e;
+        WAVE_SYNC();
+        return true;
+    }
+
+    // root table, one codeword length after the other: double what is there, then place the
+    // codewords of this length (canonical codeword number, bit-reversed, is the table index)
+    uint32_t len = 1;
+    while (len_counts[len] == 0) len++;
+    uint32_t first_code = 0;             // canonical (MSB-first) first codeword of `len`
+    uint32_t sp = offsets[0];            // index into sorted_syms of the first symbol of `len`
+    bool grown = false;
+    for (; len <= table_bits; len++) {
+        const uint32_t count = len_counts[len];
+        if (grown) {
+            const uint32_t half = 1u << (len - 1);
+            for (uint32_t i = lane; i < half; i += 64) table[half + i] = table[i];
+            WAVE_SYNC();
+        }
+        grown = true;
+        for (uint32_t j = lane; j < count; j += 64) {
+            const uint32_t rev = __brev(first_code + j) >> (32 - len);
+            table[rev] = make_entry(kind, sorted_syms[sp + j], len);
+        }
+        WAVE_SYNC();
+        sp += count;
+        first_code = (first_code + count) << 1;
+    }
+    if (sp >= offsets[max_codeword_len]) return true;   // no codeword is longer than the root index
+
+    // subtables (codewords longer than table_bits), in canonical order as the serial build;
+    // `len` is the first length behind the root, first_code its first codeword
+    while (len_counts[len] == 0) {
+        len++;
+        first_code <<= 1;
+    }
+    uint32_t codeword = __brev(first_code) >> (32 - len);
+    uint32_t cur_table_end = 1u << table_bits;
+    uint32_t subtable_prefix = ~0u;
+    uint32_t subtable_start = 0;
+    for (;;) {
+        if ((codeword & ((1u << table_bits) - 1)) != subtable_prefix) {
+            subtable_prefix = codeword & ((1u << table_bits) - 1);
+            subtable_start = cur_table_end;
+            uint32_t subtable_bits = len - table_bits;
+            uint32_t sub_used = len_counts[len];
+            while (sub_used < (1u << subtable_bits)) {
+                subtable_bits++;
+                sub_used = (sub_used << 1) +
+                           (table_bits + subtable_bits <= 15 ? len_counts[table_bits + subtable_bits] : 0);
+            }
+            cur_table_end = subtable_start + (1u << subtable_bits);
+            if (lane == 0)
+                table[subtable_prefix] = (subtable_start << 16) | kExceptional | kSubtable |
+                                         (subtable_bits << 8) | table_bits;
+        }
+        const uint32_t e = make_entry(kind, sorted_syms[sp++], len - table_bits);
+        const uint32_t stride = 1u << (len - table_bits);
+        for (uint32_t i = subtable_start + (codeword >> table_bits) + lane * stride; i < cur_table_end;
+             i += 64 * stride)
+            table[i] = e;
+        if (codeword == (1u << len) - 1) break;
+        const uint32_t bit = 1u << (31 - __clz(codeword ^ ((1u << len) - 1)));
+        codeword &= bit - 1;
+        codeword |= bit;
+        const uint32_t left = len_counts[len] - 1;
+        WAVE_SYNC();                        // every lane has read the count before it changes
+        if (lane == 0) len_counts[len] = left;
+        WAVE_SYNC();
+        while (len_counts[len] == 0) len++;
+    }
+    WAVE_SYNC();
+    return true;
+}
+
 // 32 valid bits starting at window bit offset b
 template <class WordPtr>
 __device__ inline uint32_t fetch_bits(WordPtr win, uint32_t b)
@@ -327,8 +470,9 @@ __device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *w
     if (threadIdx.x < 4) L.win[kWinWords + threadIdx.x] = 0;
 }
 
-// Read the 14-bit dynamic header + code lengths (src/decompress/mod.rs:403-507)
-// and build the three tables.  Runs on one thread; reads bits through the
+// Read the 14-bit dynamic header + code lengths (src/decompress/mod.rs:403-507) into
+// L.hdr.lens and leave the two alphabet sizes in L.hdr.num_litlen / num_offset; the big
+// tables are built afterwards by the whole wave.  Runs on one thread; reads bits through the
 // staged window, which the caller guarantees covers the whole header
 // (a header is at most 14 + 19*3 + 320*(7+7) bits < 600 bytes).
 struct HeaderResult {
@@ -389,38 +533,29 @@ __device__ __noinline__ HeaderResult read_dynamic_header(LdsStream &L, uint32_t 
         // a run passing the end is clamped (src/decompress/mod.rs:462-467)
         while (rep-- && i < total) L.hdr.lens[i++] = (uint8_t)val;
     }
-    if (!build_decode_table(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
-                            L.hdr.sorted_syms, nullptr, L.len_counts, L.offsets))
-        return HeaderResult{RSX_BAD_DATA, b};
-    if (!build_decode_table(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
-                            L.hdr.sorted_syms, &L.litlen_tablebits, L.len_counts, L.offsets))
-        return HeaderResult{RSX_BAD_DATA, b};
+    L.hdr.num_litlen = num_litlen;
+    L.hdr.num_offset = num_offset;
     return HeaderResult{RSX_SUCCESS, b};
 }
 
-// src/decompress/mod.rs:355-401
-__device__ __noinline__ void load_static_codes(LdsStream &L)
+// src/decompress/mod.rs:355-401: the code lengths of the static code (by the wave)
+__device__ inline void load_static_lens(LdsStream &L)
 {
-    uint32_t i = 0;
-    for (; i < 144; i++) L.hdr.lens[i] = 8;
-    for (; i < 256; i++) L.hdr.lens[i] = 9;
-    for (; i < 280; i++) L.hdr.lens[i] = 7;
-    for (; i < 288; i++) L.hdr.lens[i] = 8;
-    for (; i < 320; i++) L.hdr.lens[i] = 5;
-    build_decode_table(L.offset, L.hdr.lens + 288, 32, KIND_OFFSET, kOffsetBits, 15, L.hdr.sorted_syms,
-                       nullptr, L.len_counts, L.offsets);
-    build_decode_table(L.litlen, L.hdr.lens, 288, KIND_LITLEN, kLitlenBits, 15, L.hdr.sorted_syms,
-                       &L.litlen_tablebits, L.len_counts, L.offsets);
+    for (uint32_t i = threadIdx.x & 63; i < 320; i += 64)
+        L.hdr.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+    L.hdr.num_litlen = 288;   // (every lane writes the same)
+    L.hdr.num_offset = 32;
 }
 
-// Thread-0 part of a round: when the stream is between blocks, read the next
-// block header from the staged window (src/decompress/mod.rs:225-252) and build
+// First wave's part of a round: when the stream is between blocks, lane 0 reads the next
+// block header from the staged window (src/decompress/mod.rs:225-252), then the wave builds
 // the decode tables.  Leaves L.in_block / L.stored_len / L.status / L.restage set.
-__device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64_t win_bit0)
+__device__ __noinline__ void parse_block_header(LdsStream &L, const StreamCtx &c, int64_t win_bit0)
 {
     const uint64_t end_bit = c.body_len * 8;
     uint32_t b = (uint32_t)((int64_t)L.bitpos - win_bit0);
     L.restage = 0;
+    L.hdr.plan = 0;
     // a dynamic header is at most 14 + 19*3 + 320*14 bits; have it fully staged
     if (b + 8 * 640 > kWinLimitBits && b >= 128) {
         L.restage = 1;
@@ -462,11 +597,37 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
             return;
         }
         b = r.b;
+        L.hdr.plan = 2;
     } else {
-        load_static_codes(L);
+        L.hdr.plan = 1;
     }
-    L.in_block = 1;
-    L.bitpos = (uint64_t)(win_bit0 + b);
+    L.hdr.after = b;
+}
+
+__device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64_t win_bit0)
+{
+    if (threadIdx.x == 0) parse_block_header(L, c, win_bit0);
+    WAVE_SYNC();
+    const uint32_t plan = L.hdr.plan;   // (uniform)
+    if (plan == 0) return;
+    if (plan == 1) {
+        load_static_lens(L);
+        WAVE_SYNC();
+    }
+    const uint32_t num_litlen = L.hdr.num_litlen, num_offset = L.hdr.num_offset;
+    const bool ok =
+        build_decode_table_wave(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
+                                L.hdr.sorted_syms, nullptr, L.len_counts, L.offsets) &&
+        build_decode_table_wave(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
+                                L.hdr.sorted_syms, &L.litlen_tablebits, L.len_counts, L.offsets);
+    if (threadIdx.x == 0) {
+        if (!ok) {
+            L.status = RSX_BAD_DATA;
+        } else {
+            L.in_block = 1;
+            L.bitpos = (uint64_t)(win_bit0 + (int64_t)L.hdr.after);
+        }
+    }
 }
 
 // ---- the symbol decoder ------------------------------------------------------------
@@ -1081,7 +1242,7 @@ __global__ __launch_bounds__(kT, 4) void inflate_kernel(
         if (!L.in_block) {
             STAT_BEGIN();
             WG_SYNC();
-            if (tid == 0) header_step(*(LdsStream *)&L, c, win_bit0);
+            if (tid < 64) header_step(*(LdsStream *)&L, c, win_bit0);
             WG_SYNC();
             STAT_END(tH);
         }
