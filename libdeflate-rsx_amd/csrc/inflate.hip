@@ -48,7 +48,7 @@ constexpr int kT = 256;                       // threads per stream
 constexpr int kRingBits = 14;
 constexpr uint32_t kRing = 1u << kRingBits;   // LDS mirror of the newest output bytes
 constexpr uint32_t kRingMask = kRing - 1;
-constexpr uint32_t kWinBytes = 4096 + 256;    // staged compressed bytes per round
+constexpr uint32_t kWinBytes = 4096;          // staged compressed bytes per round: one 16-byte load per lane
 constexpr uint32_t kWinWords = kWinBytes / 4;
 // a token may start only while two dwords past its last fetch are still staged:
 // litlen fetch at b, offset fetch at most 20 bits later, each reads words w, w+1
