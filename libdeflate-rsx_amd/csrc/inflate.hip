@@ -57,7 +57,7 @@ constexpr uint32_t kSubBits = 126;            // compressed bits per lane and ro
 // one lane decodes at most kSubBits/2 matches of 258 bytes (a match token is
 // at least 2 bits), so a round that commits at least lane 0 always fits
 constexpr uint32_t kRoundOut = 16384 - 16;    // output bytes per round
-constexpr uint32_t kMaxMatches = 1536;        // match queue entries per round
+constexpr uint32_t kMaxMatches = 1792;        // match queue entries per round
 #ifndef RSX_WARM_BITS
 #define RSX_WARM_BITS 200
 #endif
@@ -75,7 +75,7 @@ constexpr uint32_t kExitStop = 1u << 30;      // ran out of input inside a token
 constexpr uint32_t kExitPosMask = (1u << 20) - 1;
 
 constexpr int kLitlenBits = 10;
-constexpr int kLitlenEnough = 1334;           // enough(288, 10, 15)
+constexpr int kLitlenEnough = 1334;           // enough(288, 10, 15): largest table any complete code needs
 constexpr int kOffsetBits = 8;
 constexpr int kOffsetEnough = 402;            // enough(32, 8, 15)
 constexpr int kPrecodeBits = 7;
@@ -129,6 +129,7 @@ struct HeaderScratch {
     uint8_t lens[288 + 32 + 140];
     uint8_t precode_lens[20];
     uint32_t num_litlen, num_offset;   // alphabet sizes of the block whose tables are being built
+    uint32_t len_counts[16], offsets[16];   // working arrays of the table build
     uint32_t plan;                     // 0 nothing to build, 1 the static code, 2 lens[] of a dynamic header
     uint32_t after;                    // window bit position behind the header
 };
@@ -136,10 +137,13 @@ struct SpecScratch {
     uint32_t sub_start[kT];       // start handed to a sub-sequence that is re-decoded
     uint16_t sub_bytes[kT], sub_nm[kT];
     uint16_t work[kT];            // compacted list of sub-sequences to re-decode
+    uint32_t lane_exit[kT];       // where each sub-sequence ended (dead once the emit pass fills the queue)
 };
 struct MatchQueue {
-    uint32_t dl[kMaxMatches];     // (dst - round_start) | len << 15
-    uint16_t dist[kMaxMatches];   // dist - 1
+    // Only where each match starts.  Its distance and length wait in the ring, in the first three
+    // of the bytes the match will produce (dist - 1 low, high, len - 3): nobody reads those bytes
+    // as data before the copy phase has written them.
+    uint16_t dst[kMaxMatches];    // dst - round_start
 };
 struct __align__(16) StreamLds {
     uint8_t ring[kRing];
@@ -151,9 +155,7 @@ struct __align__(16) StreamLds {
         SpecScratch spec;
         MatchQueue mq;
     };
-    uint32_t lane_exit[kT];
-    uint32_t len_counts[16], offsets[16];   // working arrays of the table build
-    uint32_t scan_carry[2 * (kT / 64)];
+    uint32_t scan_carry[2 * (kT / 64) + 4];   // scans and flags; the last four: the copy phase's spanning match
     uint32_t emit_error;          // min over lanes of lane << 8 | DecompressResult
     uint32_t stat_spec, stat_copy; // pass counters (STATS builds)
     uint32_t first_flag;          // first lane whose sub-sequence ends the block / the input
@@ -496,7 +498,7 @@ __device__ __noinline__ HeaderResult read_dynamic_header(LdsStream &L, uint32_t 
     }
     for (; i < 19; i++) L.hdr.precode_lens[c_precode_perm[i]] = 0;
     if (!build_decode_table(L.hdr.precode, L.hdr.precode_lens, 19, KIND_PRECODE, kPrecodeBits, 7,
-                            L.hdr.sorted_syms, nullptr, L.len_counts, L.offsets))
+                            L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets))
         return HeaderResult{RSX_BAD_DATA, b};
     const uint32_t total = num_litlen + num_offset;
     i = 0;
@@ -617,9 +619,9 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
     const uint32_t num_litlen = L.hdr.num_litlen, num_offset = L.hdr.num_offset;
     const bool ok =
         build_decode_table_wave(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
-                                L.hdr.sorted_syms, nullptr, L.len_counts, L.offsets) &&
+                                L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets) &&
         build_decode_table_wave(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
-                                L.hdr.sorted_syms, &L.litlen_tablebits, L.len_counts, L.offsets);
+                                L.hdr.sorted_syms, &L.litlen_tablebits, L.hdr.len_counts, L.hdr.offsets);
     if (threadIdx.x == 0) {
         if (!ok) {
             L.status = RSX_BAD_DATA;
@@ -833,7 +835,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     } else {
         sc = scan_span(L, start, bound, end_b, litlen_mask);
     }
-    L.lane_exit[tid] = sc.exit;
+    L.spec.lane_exit[tid] = sc.exit;
     L.spec.sub_bytes[tid] = (uint16_t)sc.bytes;
     L.spec.sub_nm[tid] = (uint16_t)sc.nm;
     WG_SYNC();
@@ -843,7 +845,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         WG_SYNC();
         uint32_t ns = guess;
         if (tid > 0) {
-            uint32_t pe = L.lane_exit[tid - 1];
+            uint32_t pe = L.spec.lane_exit[tid - 1];
             if (!(pe & (kExitEob | kExitStop))) ns = pe;
         }
         const bool need = ns != start;
@@ -875,13 +877,13 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             } else {
                 r = scan_span(L, st_i, bound_i, end_b, litlen_mask);
             }
-            L.lane_exit[i] = r.exit;
+            L.spec.lane_exit[i] = r.exit;
             L.spec.sub_bytes[i] = (uint16_t)r.bytes;
             L.spec.sub_nm[i] = (uint16_t)r.nm;
         }
     }
     WG_SYNC();
-    sc.exit = L.lane_exit[tid];
+    sc.exit = L.spec.lane_exit[tid];
     sc.bytes = L.spec.sub_bytes[tid];
     sc.nm = L.spec.sub_nm[tid];
     WG_SYNC();
@@ -906,9 +908,10 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     wg_exclusive_scan2(L, sc.bytes, sc.nm, &ex_bytes, &ex_nm);
     const bool commit = live && ex_bytes + sc.bytes <= kRoundOut && ex_nm + sc.nm <= kMaxMatches;
     // `commit` is monotone over lanes; the last committed lane publishes the round
-    L.lane_exit[tid] = commit ? sc.exit | 0x10000000u : sc.exit;
+    L.spec.lane_exit[tid] = commit ? sc.exit | 0x10000000u : sc.exit;
     WG_SYNC();
-    const bool last = commit && (tid == kT - 1 || !(L.lane_exit[tid + 1] & 0x10000000u));
+    const bool last = commit && (tid == kT - 1 || !(L.spec.lane_exit[tid + 1] & 0x10000000u));
+    WG_SYNC();   // the match queue shares its storage with the arrays read above
 
     if (RSX_DEV_TIMERS == 1 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tq; tq = t; }
     // ---- emit -------------------------------------------------------------------------
@@ -933,8 +936,10 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             const bool bad = e >= 0;
             if (lit && !bad) L.ring[(op + c.shift) & kRingMask] = (uint8_t)o.value;
             if (mat && !bad) {
-                L.mq.dl[mi] = (op - round_start) | (o.len << 15);
-                L.mq.dist[mi] = (uint16_t)(o.value - 1);
+                L.mq.dst[mi] = (uint16_t)(op - round_start);
+                L.ring[(op + c.shift) & kRingMask] = (uint8_t)(o.value - 1);
+                L.ring[(op + c.shift + 1) & kRingMask] = (uint8_t)((o.value - 1) >> 8);
+                L.ring[(op + c.shift + 2) & kRingMask] = (uint8_t)(o.len - 3);
             }
             op += bad ? 0u : lit ? 1u : mat ? o.len : 0u;
             mi += (mat && !bad) ? 1u : 0u;
@@ -980,7 +985,11 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     constexpr uint32_t kBack = 32768;   // pointer value v refers to position sub_start - kBack + v
     uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
     WG_SYNC();
-    for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub) {
+    // a match that runs from one step into the next: the second step finds its distance and
+    // length here (its first bytes in the ring are data by then); slots alternate between steps
+    uint32_t *span = &L.scan_carry[2 * (kT / 64)];   // [2][2] words
+    uint32_t step = 0;
+    for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub, step++) {
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
         static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
@@ -989,13 +998,26 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
         // The lane that sees the last match ending inside this step publishes the next
         // step's mcur (matches do not overlap, so "ends inside" is monotone).
+        auto info_len = [&](uint32_t dst) { return (uint32_t)L.ring[(dst + c.shift + 2) & kRingMask] + 3; };
         for (uint32_t m = mcur + tid; m < nm; m += kT) {
-            const uint32_t q = L.mq.dl[m];
-            const uint32_t dst = round_start + (q & 0x7FFF), len = q >> 15;
+            const uint32_t dst = round_start + L.mq.dst[m];
+            const bool carried = dst < sub_start;   // (only the first match of a step can be)
+            uint32_t len, dist;
+            if (carried) {
+                dist = span[(step & 1) * 2];
+                len = span[(step & 1) * 2 + 1];
+            } else {
+                dist = ((uint32_t)L.ring[(dst + c.shift) & kRingMask] |
+                        (uint32_t)L.ring[(dst + c.shift + 1) & kRingMask] << 8) + 1;
+                len = info_len(dst);
+            }
             const bool ends_here = dst + len <= sub_end;
             if (m == mcur && !ends_here) L.scan_carry[0] = mcur;
             if (dst >= sub_end) break;
-            const uint32_t dist = (uint32_t)L.mq.dist[m] + 1;
+            if (!ends_here) {
+                span[((step + 1) & 1) * 2] = dist;
+                span[((step + 1) & 1) * 2 + 1] = len;
+            }
             const uint32_t from = dst > sub_start ? dst : sub_start;
             const uint32_t to = dst + len < sub_end ? dst + len : sub_end;
             // source position p - dist, encoded relative to sub_start - kBack
@@ -1004,8 +1026,8 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             if (ends_here) {
                 bool next_ends = false;
                 if (m + 1 < nm) {
-                    const uint32_t q1 = L.mq.dl[m + 1];
-                    next_ends = round_start + (q1 & 0x7FFF) + (q1 >> 15) <= sub_end;
+                    const uint32_t dst1 = round_start + L.mq.dst[m + 1];
+                    next_ends = dst1 + info_len(dst1) <= sub_end;
                 }
                 if (!next_ends) L.scan_carry[0] = m + 1;
             }
@@ -1163,7 +1185,7 @@ __device__ ContainerInfo parse_container(int format, const uint8_t *in, uint64_t
 // stats[item*8 + k]: 0 rounds, 1 speculation passes, 2 copy passes, 3..7 cycles in
 // stage / header / decode / copy / flush
 template <bool STATS>
-__global__ __launch_bounds__(kT, 4) void inflate_kernel(
+__global__ __launch_bounds__(kT, 5) void inflate_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
