@@ -916,10 +916,11 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             const uint64_t src_a = load_le64(src + 4), src_b = load_le64(src + 12);
             uint32_t dist = 0, npairs = 0;
             uint32_t *mpp = mp + (size_t)p * kPairs;
-            bool alive = true;
-            for (uint32_t depth = 0; depth < lp.max_depth; depth++) {
+            // one exit test per candidate; everything else is selects
+            uint32_t depth = 0;
+            bool go = link != 0 && link <= max_dist;
+            while (go) {
                 dist += link;
-                if (!alive || link == 0 || dist > max_dist) break;
                 const uint32_t cand = p - dist;
                 const uint8_t *m = inp(cand);
                 link = L.prev[cand & (kWindow - 1)];
@@ -933,13 +934,16 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 const bool better = l > best_len;
                 best_len = better ? l : best_len;
                 best_off = better ? dist : best_off;
-                alive = l < stop_len;                  // matchfinder.rs:825, :851
                 if (analysis && better) {
                     // matches of increasing length, nearest first; the last slot keeps the longest
                     const uint32_t slot = npairs < kPairs ? npairs : kPairs - 1;
                     mpp[slot] = l | ((dist - 1) << 9);
                     npairs = slot + 1;
                 }
+                depth++;
+                // matchfinder.rs:825, :851: stop at a nice match, at the end of the chain, of the
+                // window, of the search budget
+                go = l < stop_len && link != 0 && dist + link <= max_dist && depth < lp.max_depth;
             }
             if (best_len < 3 && older3 != 0) {
                 // length 3 only pays at short distances
