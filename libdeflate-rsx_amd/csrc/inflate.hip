@@ -676,6 +676,9 @@ struct StepOut {
     uint32_t len;    // match length when kind == 2
 };
 
+// kValues = false: only the token boundaries matter (literal bytes, lengths and distances are
+// not computed; a pending length is just "some")
+template <bool kValues = true>
 __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d, uint32_t litlen_mask)
 {
     // refill: bc >= 32 afterwards
@@ -694,7 +697,8 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d, uint32_t 
     const bool is_eob = !is_ptr && (e & kEndOfBlock) != 0;
     const uint32_t total_bits = e & 0xFF, clen = (e >> 8) & 0xFF;
     // a pointer consumes the root bits (its low byte); a final entry code + extra bits
-    const uint32_t value = ((e >> 16) & 0x7FFF) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1));
+    const uint32_t value =
+        kValues ? ((e >> 16) & 0x7FFF) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1)) : 1u;
     d.bb >>= total_bits;
     d.bc -= total_bits;
     d.b += total_bits;
@@ -763,7 +767,7 @@ __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_
     bool running = d.b < lo;
     uint32_t guess = lo;
     while (running) {
-        const StepOut o = decoder_step(L, d, litlen_mask);
+        const StepOut o = decoder_step<false>(L, d, litlen_mask);
         const bool stop = d.b > end32 || o.kind == 3;   // nothing to learn from here on
         guess = (!stop && d.tok == d.b && d.b >= lo) ? d.b : guess;
         running = !stop && (d.tok != d.b || d.b < lo);
