@@ -1047,6 +1047,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             }
             WG_SYNC();
             cur ^= 1;
+            // the entry's pointer now spans 2 * span tokens: once it leaves the decided range
+            // every token start of the batch is marked (uniform: all lanes read the same word)
+            if (entry_slot >= lim || L.jump[cur][entry_slot] >= lim) break;
         }
         DT_MARK(3);
         // emit the tokens of marked slots in position order
