@@ -981,8 +981,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     const uint32_t nm = L.num_matches;
     const uint32_t round_start = L.round_start_lo;
     const uint32_t round_end = L.round_end_lo;
-    // positions >= lds_lo are still in the ring once the round is complete
-    const int64_t lds_lo = (int64_t)round_end - (int64_t)kRing;
+    // positions less than kRing in front of round_end are still in the ring once the round is complete
     const int tid = threadIdx.x;
     uint16_t *ptr = reinterpret_cast<uint16_t *>(L.win);
     constexpr uint32_t kSelf = 0xFFFF;
@@ -1087,15 +1086,15 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (int k = 0; k < kPer; k++) {
                 byte[k] = 0;
                 if (v[k] != kSelf) {
-                    const int64_t sp = (int64_t)sub_start - kBack + (v[k] & 0xFFFF);
+                    const uint32_t sp = sub_start - kBack + (v[k] & 0xFFFF);   // positions fit 32 bits
+                    const bool far = round_end - sp > kRing;                   // has left the ring
                     // two separate reads: written as one conditional expression the compiler
                     // folds them into a single FLAT load whose address is either in LDS or in
                     // global memory
-                    const uint8_t in_ring = L.ring[((uint32_t)sp + c.shift) & kRingMask];
+                    const uint8_t in_ring = L.ring[(sp + c.shift) & kRingMask];
                     uint8_t far_byte = 0;
-                    if (sp < lds_lo)
-                        far_byte = *((const __attribute__((address_space(1))) uint8_t *)c.out + sp);
-                    byte[k] = sp >= lds_lo ? in_ring : far_byte;
+                    if (far) far_byte = *((const __attribute__((address_space(1))) uint8_t *)c.out + sp);
+                    byte[k] = far ? far_byte : in_ring;
                 }
             }
 #pragma unroll
