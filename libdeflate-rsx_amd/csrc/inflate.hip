@@ -1025,7 +1025,18 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             const uint32_t to = dst + len < sub_end ? dst + len : sub_end;
             // source position p - dist, encoded relative to sub_start - kBack
             const uint32_t bias = kBack - dist - sub_start;
-            for (uint32_t pos = from; pos < to; pos++) ptr[pos - sub_start] = (uint16_t)(pos + bias);
+            // four pointers per store: consecutive 16-bit values packed by hand (they stay below
+            // 2^16, so the pairs never carry into each other)
+            {
+                uint32_t at = from - sub_start, left = to - from;
+                const uint32_t first = (from + bias) & 0xFFFF;
+                uint32_t lo = first | (first + 1) << 16, hi = (first + 2) | (first + 3) << 16;
+                for (; left >= 4; left -= 4, at += 4, lo += 0x00040004u, hi += 0x00040004u)
+                    *reinterpret_cast<uint2 *>(ptr + at) = make_uint2(lo, hi);   // (2-byte aligned)
+                if (left >= 1) ptr[at] = (uint16_t)lo;
+                if (left >= 2) ptr[at + 1] = (uint16_t)(lo >> 16);
+                if (left >= 3) ptr[at + 2] = (uint16_t)hi;
+            }
             if (ends_here) {
                 bool next_ends = false;
                 if (m + 1 < nm) {
