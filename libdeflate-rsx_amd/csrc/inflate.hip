@@ -1031,8 +1031,13 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
                 uint32_t at = from - sub_start, left = to - from;
                 const uint32_t first = (from + bias) & 0xFFFF;
                 uint32_t lo = first | (first + 1) << 16, hi = (first + 2) | (first + 3) << 16;
-                for (; left >= 4; left -= 4, at += 4, lo += 0x00040004u, hi += 0x00040004u)
-                    *reinterpret_cast<uint2 *>(ptr + at) = make_uint2(lo, hi);   // (2-byte aligned)
+                for (; left >= 8; left -= 8, at += 8, lo += 0x00080008u, hi += 0x00080008u)
+                    *reinterpret_cast<uint4 *>(ptr + at) =
+                        make_uint4(lo, hi, lo + 0x00040004u, hi + 0x00040004u);   // (2-byte aligned)
+                if (left >= 4) {
+                    *reinterpret_cast<uint2 *>(ptr + at) = make_uint2(lo, hi);
+                    left -= 4, at += 4, lo += 0x00040004u, hi += 0x00040004u;
+                }
                 if (left >= 1) ptr[at] = (uint16_t)lo;
                 if (left >= 2) ptr[at + 1] = (uint16_t)(lo >> 16);
                 if (left >= 3) ptr[at + 2] = (uint16_t)hi;
