@@ -987,6 +987,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     constexpr uint32_t kSelf = 0xFFFF;
     constexpr uint32_t kBack = 32768;   // pointer value v refers to position sub_start - kBack + v
     uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
+    if (tid == 0) ptr[kCopySub] = (uint16_t)kSelf;   // the spare slot (a pad word of the window buffer)
     WG_SYNC();
     // a match that runs from one step into the next: the second step finds its distance and
     // length here (its first bytes in the ring are data by then); slots alternate between steps
@@ -1058,10 +1059,12 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
         // registers.  A pointer can still move while it points into the step (kBack <= v <
         // kBack + kCopySub) and is not known to have landed on a literal; one that has is
-        // marked with kLanded (bit 16, above the 16 bits the table holds).  The rounds are
-        // branch-free: settled bytes read their own slot and rewrite their own value.
+        // marked with kLanded (a bit no pointer into the step uses), in the table too, so
+        // whoever takes it over is settled at once.  The rounds are branch-free: settled bytes
+        // read a spare slot behind the table and rewrite their own value.
         constexpr int kPer = kCopySub / kT;
-        constexpr uint32_t kLanded = 0x10000;
+        constexpr uint32_t kLanded = 0x4000;
+        static_assert(kBack == 0x8000 && kCopySub <= kLanded, "kLanded is free in pointers into the step");
         uint32_t v[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; k++) v[k] = ptr[tid + k * kT];   // slots behind n hold kSelf
@@ -1072,7 +1075,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
                 const uint32_t t = v[k] - kBack;
-                v2[k] = ptr[t < kCopySub ? t : (uint32_t)tid + k * kT];
+                v2[k] = ptr[t < kCopySub ? t : kCopySub];
             }
             WG_SYNC();   // every read of this round precedes its writes
             bool moving = false;
@@ -1102,7 +1105,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (int k = 0; k < kPer; k++) {
                 byte[k] = 0;
                 if (v[k] != kSelf) {
-                    const uint32_t sp = sub_start - kBack + (v[k] & 0xFFFF);   // positions fit 32 bits
+                    const uint32_t sp = sub_start - kBack + (v[k] >= kBack ? v[k] & ~kLanded : v[k]);   // (32-bit positions)
                     const bool far = round_end - sp > kRing;                   // has left the ring
                     // two separate reads: written as one conditional expression the compiler
                     // folds them into a single FLAT load whose address is either in LDS or in
