@@ -738,6 +738,9 @@ __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, u
 // Compress one chunk (<= 256 KiB) into `out_words` (zeroed, chunk_len + kScratchPad
 // bytes).  Returns the number of bytes written (uniform over the workgroup).
 // mp / blkcost: per-workgroup buffers of the cost-based parse (levels 10-12 only).
+// kOptimal: levels 10-12 (cost-based parse); a compile-time switch keeps the recording and
+// replay code out of the kernel of the other levels
+template <bool kOptimal>
 __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, bool last_chunk,
                                    LevelParams lp, uint32_t *tok, uint32_t *out_words, uint32_t *mp,
                                    uint8_t *blkcost)
@@ -812,9 +815,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
     // Levels 10-12 run the batch loop twice: a first pass that searches, records the
     // matches and the block ends, then (after the cost-based parse) a replay pass that
     // turns the chosen steps into tokens block by block.
-    const uint32_t passes = lp.optimal && n ? 2 : 1;
+    const uint32_t passes = kOptimal && n ? 2 : 1;
     for (uint32_t pass = 0; pass < passes; pass++) {
-    const bool analysis = lp.optimal && pass == 0, replay = pass == 1;
+    const bool analysis = kOptimal && pass == 0, replay = kOptimal && pass == 1;
     uint32_t blk = 0;
     uint32_t n_eff = n;   // replay: end of the block being replayed
     if (replay) {
@@ -1176,6 +1179,7 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__rest
 }
 
 // Persistent workgroups: workgroup g compresses chunks g, g + gridDim.x, ...
+template <bool kOptimal>
 __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
@@ -1202,7 +1206,7 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
         const bool last = finish && cb + clen >= len;
         uint32_t *outw = reinterpret_cast<uint32_t *>(scratch + (size_t)ch * scratch_stride);
         uint32_t sz;
-        sz = compress_chunk(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
+        sz = compress_chunk<kOptimal>(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
         if (threadIdx.x == 0) chunk_size[ch] = sz;
         WG_SYNC();
     }
@@ -1365,7 +1369,13 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     LevelParams lp = level_params(level);
     chunk_scan_kernel<<<1, 1024, 0, e->stream>>>(in_off, (uint32_t)n, chunk_first);
     (void)hipEventRecord(e->ev_begin, e->stream);
-    deflate_chunks_kernel<<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
+    if (lp.optimal)
+        deflate_chunks_kernel<true><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
+                                                       (uint32_t)chunks, lp, scratch, stride, tokbuf,
+                                                       chunk_size, pairbuf, costbuf,
+                                                       flush == RSX_FLUSH_FINISH);
+    else
+        deflate_chunks_kernel<false><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
                                                        (uint32_t)chunks, lp, scratch, stride, tokbuf,
                                                        chunk_size, pairbuf, costbuf,
                                                        flush == RSX_FLUSH_FINISH);
