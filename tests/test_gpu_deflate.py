@@ -169,3 +169,21 @@ def test_sync_flushed_pieces_concatenate(rsx, eng):
         # FLUSH_FINISH is the ordinary raw compress
         same, _ = eng.batch_compress(pieces[-1:], rsx.FORMAT_DEFLATE, level)
         assert same[0] == last[0]
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 12])
+def test_sizes_around_every_internal_boundary(eng, level):
+    """Lengths just below, at and just above the engine's internal units -- the 1024-position batch,
+    the 64 KiB block, the stored-block limit of 65535, the 256 KiB chunk -- for compressible text,
+    zeros, a short period and incompressible bytes; checked by the oracle's and the GPU's inflater."""
+    edges = [1, 2, 3, 4, 5, 257, 258, 259, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4097,
+             32767, 32768, 32769, 65534, 65535, 65536, 65537, 131072 + 1, 262143, 262144, 262145,
+             262144 + 1024, 2 * 262144 - 1, 2 * 262144 + 1]
+    datas = []
+    for i, n in enumerate(edges):
+        kind = i % 4
+        datas.append(corpus.text(n, 900 + i) if kind == 0 else bytes(n) if kind == 1 else
+                     corpus.periodic(7, n) if kind == 2 else corpus.random_bytes(n, 950 + i))
+    # and the same lengths again with the kinds rotated
+    datas += [corpus.text(n, 990 + i) for i, n in enumerate(edges) if i % 4 != 0]
+    roundtrip(eng, datas, 0, level)
