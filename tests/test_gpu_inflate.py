@@ -181,3 +181,21 @@ def test_corrupted_streams_agree_with_oracle(eng, seed):
                 streams.append(bytes(b))
                 caps.append(n if kind != 4 else int(rs.choice([0, n // 2, n - 1, n, n + 7])))
         check_against_oracle(eng, streams, caps, fmt)
+
+
+def test_matches_across_copy_step_boundaries(eng):
+    """Long matches back to back (a 3000-byte random block repeated, so almost every token is a
+    258-byte match at distance 3000) cross the 2048-byte steps of the copy phase at every phase;
+    a few literals in between shift the alignment.  Also short periods, where one match feeds the
+    next inside a step."""
+    rs = np.random.RandomState(77)
+    block = rs.randint(0, 256, size=3000, dtype=np.uint8).tobytes()
+    datas = []
+    for shift in (0, 1, 2, 3, 7, 100, 257, 2047):
+        d = bytes(shift) + b"".join(block + bytes([k & 0xFF]) * (k % 3) for k in range(60))
+        datas.append(d)
+    datas.append(block[:5] * 40000)            # period 5, 200000 bytes: overlapping run-length copies
+    datas.append((block[:2049]) * 100)         # period one byte longer than a copy step
+    datas.append((block[:2047]) * 100)
+    streams = [zlib.compress(d, 9)[2:-4] for d in datas] + [o.compress(d, 6) for d in datas]
+    check_against_oracle(eng, streams, [len(d) for d in datas] * 2, 0)
