@@ -15,24 +15,30 @@
 // (the reference has no stored fallback above level 0).  The contract is a valid
 // stream of the same format that inflates to the input.
 //
-// One 512-thread workgroup compresses one 256 KiB chunk at a time:
-//   match   positions are taken 512 at a time.  Each lane hashes its 3 bytes,
-//           pushes its position on the hash chain (head + prev tables in LDS,
-//           16-bit positions, one LDS atomic exchange per position, waves in
-//           turn so chains stay ordered) and walks the chain of older
-//           positions, comparing against the input through L1/L2;
+// One 1024-thread workgroup per CU (156 KiB of LDS) compresses one 256 KiB chunk at a time:
+//   match   positions are taken 1024 at a time.  Each lane hashes its 4 bytes (and
+//           its 3 bytes, for a table of the newest length-3 candidates), pushes its
+//           position on the hash chain (head and distance-link tables in LDS, one
+//           LDS atomic exchange per position, waves in turn so chains stay ordered)
+//           and walks the chain of older positions, comparing 20 bytes per candidate
+//           against its own first 20 bytes held in registers; the input window is a
+//           sliding LDS copy;
 //   parse   greedy / lazy selection is a pointer chase p -> next(p); the set of
-//           token starts is found with log2(512) rounds of pointer jumping, a
-//           prefix sum places the tokens in a per-workgroup token buffer and
-//           LDS atomics build the symbol histograms;
-//   emit    per ~64 KiB block one lane builds the Huffman codes and writes the
-//           header, then all lanes compute token bit lengths, prefix-sum them
-//           and OR their code bits into the zeroed output words.
+//           token starts is found by pointer jumping (at most log2(1024) rounds,
+//           fewer when the entry's pointer leaves the batch early), a prefix sum
+//           places the tokens in a per-workgroup token buffer and LDS atomics build
+//           the symbol histograms;
+//   emit    per <= 64 KiB block the workgroup builds the Huffman codes and the
+//           header together, then all lanes compute token bit lengths, prefix-sum
+//           them and pack their code bits into the output words.
+// Levels 10-12 run the batch loop twice around a cost-based parse (see
+// optimal_parse_piece); the kernel is compiled separately for them.
 // A second kernel concatenates the chunks of each item behind the container
-// header, adds the Adler-32 / CRC-32 trailer and reports sizes and status.
+// header (or writes the item as plain stored blocks when that is smaller), adds
+// the Adler-32 / CRC-32 trailer and reports sizes and status.
 //
-// Roofline: HBM-bound by design; algorithmic bytes per item =
-// uncompressed_len + compressed_len.
+// Roofline: HBM by design (algorithmic bytes per item = uncompressed_len +
+// compressed_len); in practice bound by LDS round trips of the chain walk.
 #include "engine.h"
 
 #include <cstdlib>

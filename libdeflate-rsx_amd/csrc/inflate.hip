@@ -6,29 +6,32 @@
 // build (:1324-1495), Huffman block body + LZ copy (:509-1072), zlib / gzip
 // framing (:1074-1240).  Result codes are the reference's DecompressResult.
 //
-// One 256-thread workgroup decodes one stream in rounds:
-//   1. stage   a ~4 KiB window of compressed bytes into LDS with 16-byte
-//              coalesced loads;
-//   2. decode  all 256 lanes decode Huffman symbols at once.  The window is
-//              cut into 128-bit sub-sequences, lane i starts at a guessed bit
-//              position inside sub-sequence i and decodes until it crosses
-//              into sub-sequence i+1.  Huffman streams re-synchronise, so after
-//              a few passes of "restart where the previous lane really ended"
-//              every lane's start is the true one (lane 0 always is).  A prefix
-//              sum of the bytes each lane produces gives its output position,
-//              then each lane decodes once more and emits: literals straight
-//              into a 32 KiB LDS ring that mirrors the tail of the output,
-//              matches into a queue as (dst, len, dist);
-//   3. copy    all lanes resolve the queued matches in parallel -- a match may
-//              run once every byte below its source end is final; sources older
-//              than the ring are read back from the already written output;
+// One 256-thread workgroup decodes one stream in rounds (31 KB of LDS, so that five
+// workgroups share a CU):
+//   1. stage   a 4 KiB window of compressed bytes into LDS, one 16-byte coalesced
+//              load per lane;
+//   2. decode  all 256 lanes decode Huffman symbols at once.  The window is cut
+//              into 126-bit sub-sequences, lane i starts at a guessed bit position
+//              inside sub-sequence i (the end of a short warm-up decode in front
+//              of it) and decodes until it crosses into sub-sequence i+1.  Huffman
+//              streams re-synchronise, so after a few passes of "restart where the
+//              previous lane really ended" every lane's start is the true one
+//              (lane 0 always is).  A prefix sum of the bytes each lane produces
+//              gives its output position, then each lane decodes once more and
+//              emits: literals straight into a 16 KiB LDS ring that mirrors the
+//              tail of the output, matches as a queue of start positions with
+//              distance and length parked in the ring bytes the match will fill;
+//   3. copy    all lanes resolve the queued matches in parallel, 2048 output
+//              bytes at a time, by pointer jumping over per-byte source pointers;
+//              sources older than the ring are read back from the already
+//              written output;
 //   4. flush   the round's bytes leave the ring as 16-byte coalesced stores.
-// Block headers and decode tables are still handled by one lane.
+// Block headers are read by one lane; the decode tables are built by the first wave.
 // HBM traffic is therefore one read of the compressed bytes and one write of
 // the output; the history window is served from LDS (and L2 for far matches).
 //
-// Roofline: HBM-bound by design, algorithmic bytes per stream =
-// compressed_len + uncompressed_len.
+// Roofline: HBM by design (algorithmic bytes per stream = compressed_len +
+// uncompressed_len); in practice the kernel is bound by vector-ALU issue.
 #include "engine.h"
 
 #include <cstdlib>
