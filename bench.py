@@ -154,10 +154,10 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     total_out = int(sz.sum())
     job_bytes = total_in + total_out
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=args.reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        b = torch.tensor([job_bytes], dtype=torch.int64, device=dev)
+        b = torch.tensor([job_bytes], dtype=torch.int64, device=args.reduce_device)
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         job_bytes = int(b.item())
     if rank == 0:
@@ -228,10 +228,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # RSX_BENCH_REHEARSE=1: a rehearsal of the multi-rank path on a box with fewer GPUs than ranks --
+    # ranks share the GPUs that exist and the two reductions run over gloo.  Not a measurement.
+    rehearse = os.environ.get("RSX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    args.reduce_device = torch.device("cpu") if rehearse else dev
 
     if args.op == "compress":
         return bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev)
@@ -318,10 +327,10 @@ def main():
                          % (np.unique(st), len(bad), bad[:8], st[bad[:8]], sz[bad[:8]]))
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=args.reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        b = torch.tensor([total_in + total_out], dtype=torch.int64, device=dev)
+        b = torch.tensor([total_in + total_out], dtype=torch.int64, device=args.reduce_device)
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         job_bytes = int(b.item())
     else:
