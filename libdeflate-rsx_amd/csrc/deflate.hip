@@ -1046,7 +1046,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             uint32_t j = L.jump[cur][s];
             uint32_t jx = (tid == kCT - 1) ? L.jump[cur][kCT] : kEnd;
             bool mk = L.mark[s] != 0, mkx = (tid == kCT - 1) && L.mark[kCT] != 0;
-            WG_SYNC();
+            // no barrier between reading and setting marks: a slot that sees its own mark set
+            // earlier in the same step only marks its successor (a token start as well) a step
+            // early; the jump tables are double-buffered
             if (mk && j < lim) L.mark[j] = 1;
             if (mkx && jx < lim) L.mark[jx] = 1;
             L.jump[cur ^ 1][s] = L.jump[cur][j];
