@@ -1028,16 +1028,16 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         }
         // pointer jumping over slots 0..kCT (slot kCT+1 = beyond)
         const uint32_t entry_slot = entry - base_pos;   // entry >= base_pos (b0 = 0: entry 0 -> slot 1)
+        // every slot's owner sets its mark: 1 only for the slot the parse enters the batch at
+        const uint32_t enter = entry_slot < lim ? entry_slot : ~0u;
         L.jump[0][tid] = (uint16_t)(my_next > kEnd ? kEnd : my_next);
-        L.mark[tid] = 0;
+        L.mark[tid] = (uint32_t)tid == enter;
         if (tid == kCT - 1) {
             L.jump[0][kCT] = (uint16_t)(x_next > kEnd ? kEnd : x_next);
             L.jump[0][kEnd] = (uint16_t)kEnd;
-            L.mark[kCT] = 0;
+            L.mark[kCT] = enter == (uint32_t)kCT;
             L.mark[kEnd] = 0;
         }
-        WG_SYNC();
-        if (tid == 0 && entry_slot < lim) L.mark[entry_slot] = 1;
         WG_SYNC();
         int cur = 0;
         for (uint32_t span = 1; span < kCT + 2; span <<= 1) {
