@@ -144,7 +144,9 @@ int rsx_adler32(rsx_engine *e, uint32_t adler, const uint8_t *data, size_t len, 
  * data already lives in HBM.  total_in = in_off[n] - in_off[0], max_item (the
  * largest item's input length) and, for decompress, total_out / max_out (sum
  * and maximum of the output slot sizes) are host-known scalars used to size
- * the launch and the workspace.  Items must be smaller than 4 GiB.
+ * the launch and the workspace.  Items must be smaller than 4 GiB.  A max_item
+ * smaller than the longest item costs compression, not safety: such items are
+ * written as stored blocks (or report InsufficientSpace).
  */
 int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_t *in,
                               const uint64_t *in_off, size_t n, uint64_t total_in,

@@ -1213,6 +1213,12 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
         // FlushMode::Sync leaves the item's stream open: every chunk ends byte aligned, none is final
         const bool last = finish && cb + clen >= len;
         uint32_t *outw = reinterpret_cast<uint32_t *>(scratch + (size_t)ch * scratch_stride);
+        if ((uint64_t)clen + kScratchPad > scratch_stride) {
+            // the caller understated the longest item: never write past the chunk's slot; the
+            // size makes the item fall back to stored blocks or report InsufficientSpace (uniform)
+            if (threadIdx.x == 0) chunk_size[ch] = 0x7FFFFFFFu;
+            continue;
+        }
         uint32_t sz;
         sz = compress_chunk<kOptimal>(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
         if (threadIdx.x == 0) chunk_size[ch] = sz;
@@ -1326,12 +1332,18 @@ uint64_t chunk_upper_bound(size_t n, uint64_t total_in) { return total_in / kChu
 // upper bound on the workgroups deflate_launch starts
 static uint32_t deflate_grid_bound(uint64_t chunks) { return (uint32_t)(chunks < 1024 ? chunks : 1024); }
 
+// bytes of scratch per chunk: no chunk is longer than the longest item
+static uint64_t scratch_stride(uint64_t max_item)
+{
+    const uint64_t longest = max_item < kChunk ? max_item : kChunk;
+    return align_up(longest, 256) + kScratchPad;
+}
+
 size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int level)
 {
-    (void)max_item;
     const uint64_t chunks = chunk_upper_bound(n, total_in);
     const size_t pairs = level >= 10 ? align_up((size_t)deflate_grid_bound(chunks) * kChunk * kPairs * 4, 256) : 0;
-    const uint64_t stride = kChunk + kScratchPad;
+    const uint64_t stride = scratch_stride(max_item);
     return align_up(chunks * stride, 256) + align_up((chunks + 1) * 4, 256) * 2 +
            align_up((n + 1) * 4, 256) + align_up((size_t)1024 * kTokCap * 4, 256) +
            checksum_ws_bytes(n, total_in) + pairs +
@@ -1353,7 +1365,7 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
         g_num_cus = prop.multiProcessorCount;
     }
     const uint64_t chunks = chunk_upper_bound(n, total_in);
-    const uint64_t stride = kChunk + kScratchPad;
+    const uint64_t stride = scratch_stride(max_item);
     uint32_t grid = (uint32_t)(chunks < (uint64_t)g_num_cus ? chunks : (uint64_t)g_num_cus);
     if (grid > 1024) grid = 1024;
     uint8_t *scratch = static_cast<uint8_t *>(ws_take(e, chunks * stride));

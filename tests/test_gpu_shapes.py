@@ -141,3 +141,38 @@ def test_repeated_compress_batches_are_identical(eng):
         assert comp12[i] == comp12[i % 16], i
     for i in range(16):
         assert zlib.decompress(comp12[i], -15) == datas[i]
+
+
+def test_understated_longest_item_never_overruns(eng, rsx):
+    # the device entry point sizes its per-chunk scratch from the caller's `max_item`; a caller
+    # that understates it must get stored blocks or InsufficientSpace for the long items, never a
+    # write outside a slot: every item still inflates to its input or reports status 1
+    import torch
+    dev = torch.device("cuda", 0)
+    datas = [corpus.text(4096, 700), corpus.text(200000, 701), corpus.text(3000, 702), corpus.text(70000, 703)]
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.uint64)
+    in_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=in_off[1:])
+    bounds = np.array([rsx.compress_bound(0, len(d)) for d in datas], dtype=np.uint64)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(bounds, out=out_off[1:])
+    d_in = torch.from_numpy(np.frombuffer(b"".join(datas), dtype=np.uint8).copy()).to(dev)
+    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
+    d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
+    d_out = torch.zeros(int(out_off[-1]) + 4096, dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    e2 = rsx.Engine(0, torch.cuda.current_stream(dev).cuda_stream)
+    e2.batch_compress_device(rsx.FORMAT_DEFLATE, 6, d_in.data_ptr(), d_in_off.data_ptr(), n, int(in_off[-1]),
+                             4096, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                             d_status.data_ptr())   # max_item claims 4096; two items are far longer
+    torch.cuda.synchronize(dev)
+    st, sz, out = d_status.cpu().numpy(), d_sizes.cpu().numpy(), d_out.cpu().numpy()
+    assert (out[int(out_off[-1]):] == 0).all()
+    for i, d in enumerate(datas):
+        assert st[i] in (0, 1)
+        if st[i] == 0:
+            c = out[int(out_off[i]):int(out_off[i]) + int(sz[i])].tobytes()
+            assert zlib.decompress(c, -15) == d
+    assert st[0] == 0 and st[2] == 0
