@@ -50,9 +50,13 @@ struct DeviceGuard {
     }
 };
 
+// argument errors are reported before the engine's lock is taken: take it for the message
 int bad(rsx_engine *e, const char *msg)
 {
-    if (e) e->err = msg;
+    if (e) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->err = msg;
+    }
     return RSX_E_INVALID;
 }
 
@@ -236,6 +240,7 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
     BatchShape si, so;
     if (!shape_of(in_off, n, &si)) return bad(e, "in_off not monotonic");
     if (out_off && !shape_of(out_off, n, &so)) return bad(e, "out_off not monotonic");
+    if ((!in && si.total) || (out_off && !out && so.total)) return bad(e, "null pointer");
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
 
@@ -259,11 +264,18 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
         s.d_values = static_cast<uint32_t *>(ws_take(e, n * sizeof(uint32_t)));
     }
 
+    if (!s.d_in || !s.d_in_off || (out_off && (!s.d_out || !s.d_out_off || !s.d_sizes || !s.d_status)) ||
+        (!out_off && !s.d_values)) {
+        e->err = "workspace carve failed";
+        return RSX_E_NOMEM;
+    }
+
     // rebase offsets to the staged copies
-    std::string &err = e->err;
-    (void)err;
     uint64_t *h_off = new (std::nothrow) uint64_t[2 * (n + 1)];
-    if (!h_off) return RSX_E_NOMEM;
+    if (!h_off) {
+        e->err = "host allocation of the offset arrays failed";
+        return RSX_E_NOMEM;
+    }
     for (size_t i = 0; i <= n; i++) h_off[i] = in_off[i] - in_off[0];
     if (out_off)
         for (size_t i = 0; i <= n; i++) h_off[n + 1 + i] = out_off[i] - out_off[0];
@@ -303,14 +315,26 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
         // copy back only what each item produced; sizes are validated against the
         // slot like src/batch_cuda.rs:123-137 does before touching the payload
         for (size_t i = 0; i < n; i++) {
-            uint64_t slot = out_off[i + 1] - out_off[i];
-            if (out_sizes[i] > slot) {
+            if (out_sizes[i] > out_off[i + 1] - out_off[i]) {
                 e->err = "device returned a size larger than its slot";
                 return RSX_E_DEVICE;
             }
-            if (status[i] == 0 && out_sizes[i])
-                RSX_HIP(e, hipMemcpyAsync(out + out_off[i], s.d_out + (out_off[i] - out_off[0]),
-                                          out_sizes[i], hipMemcpyDeviceToHost, e->stream));
+        }
+        // items that fill their slots to the last byte (decompression into exact-size slots)
+        // are adjacent in both buffers: one copy per run of them, not one per item
+        uint64_t run_at = 0, run_len = 0;   // pending copy, relative to out_off[0]
+        for (size_t i = 0; i <= n; i++) {
+            const bool have = i < n && status[i] == 0 && out_sizes[i];
+            const uint64_t at = i < n ? out_off[i] - out_off[0] : 0;
+            if (run_len && (!have || at != run_at + run_len)) {
+                RSX_HIP(e, hipMemcpyAsync(out + out_off[0] + run_at, s.d_out + run_at, run_len,
+                                          hipMemcpyDeviceToHost, e->stream));
+                run_len = 0;
+            }
+            if (have) {
+                if (!run_len) run_at = at;
+                run_len += out_sizes[i];
+            }
         }
         RSX_HIP(e, hipStreamSynchronize(e->stream));
     } else {

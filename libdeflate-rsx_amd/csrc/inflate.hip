@@ -81,16 +81,28 @@ constexpr int kLitlenBits = 10;
 constexpr int kLitlenEnough = 1334;           // enough(288, 10, 15): largest table any complete code needs
 constexpr int kOffsetBits = 8;
 constexpr int kOffsetEnough = 402;            // enough(32, 8, 15)
+static_assert(kOffsetEnough <= 512, "the offset table sits in front of the litlen table at index 512");
 constexpr int kPrecodeBits = 7;
 constexpr int kPrecodeEnough = 128;
 
-// decode-table entry flags (same meaning as src/decompress/tables.rs:32-35)
-constexpr uint32_t kLiteral = 0x80000000u;
-constexpr uint32_t kExceptional = 0x00008000u;
-constexpr uint32_t kSubtable = 0x00004000u;
-constexpr uint32_t kEndOfBlock = 0x00002000u;
+// Decode-table entries of the litlen and offset tables.  They hold what the entries of
+// src/decompress/tables.rs:32-53 hold (symbol value, codeword length, codeword + extra bits)
+// and, in addition, the table the NEXT lookup uses, so that a decoder step derives its next
+// state from the entry alone:
+//   bits  0-4   bits the step consumes (codeword + extra bits; for a pointer: the root index)
+//   bits  5-8   codeword bits among them (the rest are extra bits)
+//   bits  9-10  what the step finishes: kTokNone / kTokEob / kTokLit / kTokMatch
+//   bit  11     the next lookup is the litlen root (the flag is that table's byte offset, 4 * kTabLitlen)
+//   bits 12-15  index width of the next lookup
+//   bits 16-30  literal / length base / distance base / byte offset of the subtable
+//   bit  31     subtable pointer
+constexpr uint32_t kTokNone = 0, kTokEob = 1, kTokLit = 2, kTokMatch = 3;
+constexpr uint32_t kEntNextLit = 1u << 11;
+constexpr uint32_t kEntPointer = 1u << 31;
+constexpr uint32_t kTabLitlen = 512;          // the offset table sits at table index 0, the litlen table here
+static_assert(4 * kTabLitlen == kEntNextLit, "the flag is the table's byte offset");
 
-enum { KIND_PRECODE = 0, KIND_LITLEN = 1, KIND_OFFSET = 2 };
+enum { KIND_LITLEN = 1, KIND_OFFSET = 2 };
 
 __constant__ uint16_t c_len_base[31] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,
                                         17, 19, 23, 27, 31, 35, 43, 51, 59,  67,  83,
@@ -106,22 +118,23 @@ __constant__ uint8_t c_off_extra[32] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,  4,
 __constant__ uint8_t c_precode_perm[19] = {16, 17, 18, 0, 8,  7, 9,  6, 10, 5,
                                            11, 4,  12, 3, 13, 2, 14, 1, 15};
 
-// per-symbol decode results, src/decompress/tables.rs:10-30, :55-379
-__device__ inline uint32_t decode_result(int kind, uint32_t sym)
+// per-symbol decode results, src/decompress/tables.rs:10-30, :55-379; `len` = codeword bits
+// this entry accounts for, `root_bits` = index width of the litlen root table
+__device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t len, uint32_t root_bits)
 {
-    if (kind == KIND_PRECODE) return sym << 16;
+    const uint32_t back = kEntNextLit | (root_bits << 12);   // the next token starts at the litlen root
     if (kind == KIND_LITLEN) {
-        if (sym < 256) return kLiteral | (sym << 16);
-        if (sym == 256) return kExceptional | kEndOfBlock;
-        return ((uint32_t)c_len_base[sym - 257] << 16) | c_len_extra[sym - 257];
+        if (sym < 256) return (sym << 16) | (kTokLit << 9) | back | (len << 5) | len;
+        if (sym == 256) return (kTokEob << 9) | back | (len << 5) | len;
+        // a length: its distance comes from the offset root
+        return ((uint32_t)c_len_base[sym - 257] << 16) | (kTokNone << 9) | ((uint32_t)kOffsetBits << 12) | (len << 5) |
+               (len + c_len_extra[sym - 257]);
     }
-    return ((uint32_t)c_off_base[sym] << 16) | c_off_extra[sym];
+    return ((uint32_t)c_off_base[sym] << 16) | (kTokMatch << 9) | back | (len << 5) | (len + c_off_extra[sym]);
 }
 
-__device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t len)
-{
-    return decode_result(kind, sym) + (len << 8) + len;
-}
+// the precode's entries: symbol << 16 | codeword length
+__device__ inline uint32_t make_precode_entry(uint32_t sym, uint32_t len) { return (sym << 16) | len; }
 
 // Everything a workgroup keeps in LDS.  Three groups of arrays are never live at
 // the same time and share storage: header parsing scratch, the per-sub-sequence
@@ -151,8 +164,7 @@ struct MatchQueue {
 struct __align__(16) StreamLds {
     uint8_t ring[kRing];
     uint32_t win[kWinWords + 4];      // staged input; reused as u16 source pointers by the copy phase
-    uint32_t litlen[kLitlenEnough];   // litlen and offset tables are adjacent: the decode
-    uint32_t offset[kOffsetEnough];   // loops index both relative to litlen[0]
+    uint32_t tab[kTabLitlen + kLitlenEnough];   // decode tables: offset at index 0, litlen at kTabLitlen
     union {
         HeaderScratch hdr;
         SpecScratch spec;
@@ -180,22 +192,19 @@ struct __align__(16) StreamLds {
 #define RSX_LDS __attribute__((address_space(3)))
 typedef RSX_LDS StreamLds LdsStream;
 
-// Serial decode-table build; restates src/decompress/mod.rs:1324-1495 (called by
-// one thread).  Returns false when the code-length set is rejected.  len_counts and
-// offsets are 16 words of scratch each.
-__device__ __noinline__ bool build_decode_table(RSX_LDS uint32_t *table, const RSX_LDS uint8_t *lens,
-                                                uint32_t num_syms, int kind, uint32_t table_bits,
-                                                uint32_t max_codeword_len, RSX_LDS uint16_t *sorted_syms,
-                                                RSX_LDS uint32_t *table_bits_ret,
-                                                RSX_LDS uint32_t *len_counts, RSX_LDS uint32_t *offsets)
+// Serial decode-table build for the precode (19 symbols, codewords of at most 7 bits = the
+// table index, so no subtables); restates src/decompress/mod.rs:1324-1495 for that case (called
+// by one thread).  Returns false when the code-length set is rejected.  len_counts and offsets
+// are 16 words of scratch each.
+__device__ __noinline__ bool build_precode_table(RSX_LDS uint32_t *table, const RSX_LDS uint8_t *lens,
+                                                 RSX_LDS uint16_t *sorted_syms, RSX_LDS uint32_t *len_counts,
+                                                 RSX_LDS uint32_t *offsets)
 {
+    const uint32_t num_syms = 19, table_bits = kPrecodeBits;
+    uint32_t max_codeword_len = 7;
     for (int i = 0; i < 16; i++) len_counts[i] = 0;
     for (uint32_t s = 0; s < num_syms; s++) len_counts[lens[s]]++;
     while (max_codeword_len > 1 && len_counts[max_codeword_len] == 0) max_codeword_len--;
-    if (table_bits_ret) {
-        if (table_bits > max_codeword_len) table_bits = max_codeword_len;
-        *table_bits_ret = table_bits;
-    }
     offsets[0] = 0;
     offsets[1] = len_counts[0];
     uint32_t codespace_used = 0;
@@ -215,7 +224,7 @@ __device__ __noinline__ bool build_decode_table(RSX_LDS uint32_t *table, const R
             if (codespace_used != (1u << (max_codeword_len - 1)) || len_counts[1] != 1) return false;
             s = sorted_syms[offsets[0]];
         }
-        uint32_t e = make_entry(kind, s, 1);
+        uint32_t e = make_precode_entry(s, 1);
         for (uint32_t i = 0; i < (1u << table_bits); i++) table[i] = e;
         return true;
     }
@@ -228,7 +237,7 @@ __device__ __noinline__ bool build_decode_table(RSX_LDS uint32_t *table, const R
     while (len <= table_bits) {
         uint32_t count = len_counts[len];
         while (count--) {
-            table[codeword] = make_entry(kind, *sp++, len);
+            table[codeword] = make_precode_entry(*sp++, len);
             if (codeword == cur_table_end - 1) {
                 for (; len < table_bits; len++) {
                     for (uint32_t i = 0; i < cur_table_end; i++) table[cur_table_end + i] = table[i];
@@ -246,53 +255,27 @@ __device__ __noinline__ bool build_decode_table(RSX_LDS uint32_t *table, const R
                 cur_table_end <<= 1;
             }
         } while (len <= table_bits && len_counts[len] == 0);
-        if (len > table_bits)
-            while (len_counts[len] == 0) len++;
     }
-
-    cur_table_end = 1u << table_bits;
-    uint32_t subtable_prefix = ~0u;
-    uint32_t subtable_start = 0;
-    for (;;) {
-        if ((codeword & ((1u << table_bits) - 1)) != subtable_prefix) {
-            subtable_prefix = codeword & ((1u << table_bits) - 1);
-            subtable_start = cur_table_end;
-            uint32_t subtable_bits = len - table_bits;
-            uint32_t sub_used = len_counts[len];
-            while (sub_used < (1u << subtable_bits)) {
-                subtable_bits++;
-                sub_used = (sub_used << 1) +
-                           (table_bits + subtable_bits <= 15 ? len_counts[table_bits + subtable_bits] : 0);
-            }
-            cur_table_end = subtable_start + (1u << subtable_bits);
-            table[subtable_prefix] = (subtable_start << 16) | kExceptional | kSubtable |
-                                     (subtable_bits << 8) | table_bits;
-        }
-        uint32_t e = make_entry(kind, *sp++, len - table_bits);
-        uint32_t stride = 1u << (len - table_bits);
-        for (uint32_t i = subtable_start + (codeword >> table_bits); i < cur_table_end; i += stride)
-            table[i] = e;
-        if (codeword == (1u << len) - 1) return true;
-        uint32_t bit = 1u << (31 - __clz(codeword ^ ((1u << len) - 1)));
-        codeword &= bit - 1;
-        codeword |= bit;
-        len_counts[len]--;
-        while (len_counts[len] == 0) len++;
-    }
+    return false;   // not reached: a complete code ends on the all-ones codeword above
 }
 
 // Orders the LDS traffic of one wave: its lanes run in step and the LDS serves a wave's
 // requests in order, so this only has to keep the compiler from moving accesses across.
 #define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// The same table (src/decompress/mod.rs:1324-1495, entry for entry) built by the 64 lanes
-// of one wave.  Everything that decides the layout -- code-space checks, the canonical
-// first codeword of each length, the sizes and places of the subtables -- is computed
-// alike by every lane; the lanes share the counting, the sorting of the symbols, the
-// placing of the codewords of one length and the doubling of the table between lengths.
-__device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, const RSX_LDS uint8_t *lens,
-                                                     uint32_t num_syms, int kind, uint32_t table_bits,
-                                                     uint32_t max_codeword_len, RSX_LDS uint16_t *sorted_syms,
+// The litlen or offset table (src/decompress/mod.rs:1324-1495: same checks, same root and
+// subtable layout, the entries in this file's format) built by the 64 lanes of one wave.
+// Everything that decides the layout -- code-space checks, the canonical first codeword of
+// each length, the sizes and places of the subtables -- is computed alike by every lane; the
+// lanes share the counting, the sorting of the symbols, the placing of the codewords of one
+// length and the doubling of the table between lengths.  `table_index` is where table[0] sits
+// in the decoder's table space (subtable pointers are absolute byte offsets); `root_bits` the index width of
+// the litlen root, for the entries that lead back to it (ignored when table_bits_ret is given:
+// then this IS the litlen table and its own shrunk width is used and returned).
+__device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, uint32_t table_index,
+                                                     const RSX_LDS uint8_t *lens, uint32_t num_syms, int kind,
+                                                     uint32_t table_bits, uint32_t max_codeword_len,
+                                                     uint32_t root_bits, RSX_LDS uint16_t *sorted_syms,
                                                      RSX_LDS uint32_t *table_bits_ret,
                                                      RSX_LDS uint32_t *len_counts, RSX_LDS uint32_t *offsets)
 {
@@ -307,6 +290,7 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, co
     if (table_bits_ret) {
         if (table_bits > max_codeword_len) table_bits = max_codeword_len;
         if (lane == 0) *table_bits_ret = table_bits;
+        root_bits = table_bits;
     }
     // offsets[len] = where the symbols of that length start in sorted_syms
     uint32_t codespace_used = 0;
@@ -345,7 +329,7 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, co
             if (codespace_used != (1u << (max_codeword_len - 1)) || len_counts[1] != 1) return false;
             s = sorted_syms[offsets[0]];
         }
-        const uint32_t e = make_entry(kind, s, 1);
+        const uint32_t e = make_entry(kind, s, 1, root_bits);
         for (uint32_t i = lane; i < (1u << table_bits); i += 64) table[i] = e;
         WAVE_SYNC();
         return true;
@@ -368,7 +352,7 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, co
         grown = true;
         for (uint32_t j = lane; j < count; j += 64) {
             const uint32_t rev = __brev(first_code + j) >> (32 - len);
-            table[rev] = make_entry(kind, sorted_syms[sp + j], len);
+            table[rev] = make_entry(kind, sorted_syms[sp + j], len, root_bits);
         }
         WAVE_SYNC();
         sp += count;
@@ -399,10 +383,10 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, co
             }
             cur_table_end = subtable_start + (1u << subtable_bits);
             if (lane == 0)
-                table[subtable_prefix] = (subtable_start << 16) | kExceptional | kSubtable |
-                                         (subtable_bits << 8) | table_bits;
+                table[subtable_prefix] = kEntPointer | (4 * (table_index + subtable_start) << 16) |
+                                         (subtable_bits << 12) | (table_bits << 5) | table_bits;
         }
-        const uint32_t e = make_entry(kind, sorted_syms[sp++], len - table_bits);
+        const uint32_t e = make_entry(kind, sorted_syms[sp++], len - table_bits, root_bits);
         const uint32_t stride = 1u << (len - table_bits);
         for (uint32_t i = subtable_start + (codeword >> table_bits) + lane * stride; i < cur_table_end;
              i += 64 * stride)
@@ -500,8 +484,8 @@ __device__ __noinline__ HeaderResult read_dynamic_header(LdsStream &L, uint32_t 
         b += 3;
     }
     for (; i < 19; i++) L.hdr.precode_lens[c_precode_perm[i]] = 0;
-    if (!build_decode_table(L.hdr.precode, L.hdr.precode_lens, 19, KIND_PRECODE, kPrecodeBits, 7,
-                            L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets))
+    if (!build_precode_table(L.hdr.precode, L.hdr.precode_lens, L.hdr.sorted_syms, L.hdr.len_counts,
+                             L.hdr.offsets))
         return HeaderResult{RSX_BAD_DATA, b};
     const uint32_t total = num_litlen + num_offset;
     i = 0;
@@ -620,11 +604,14 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
         WAVE_SYNC();
     }
     const uint32_t num_litlen = L.hdr.num_litlen, num_offset = L.hdr.num_offset;
-    const bool ok =
-        build_decode_table_wave(L.offset, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits, 15,
-                                L.hdr.sorted_syms, nullptr, L.hdr.len_counts, L.hdr.offsets) &&
-        build_decode_table_wave(L.litlen, L.hdr.lens, num_litlen, KIND_LITLEN, kLitlenBits, 15,
-                                L.hdr.sorted_syms, &L.litlen_tablebits, L.hdr.len_counts, L.hdr.offsets);
+    // the litlen table first: the offset entries carry the index width of its root
+    bool ok = build_decode_table_wave(L.tab + kTabLitlen, kTabLitlen, L.hdr.lens, num_litlen, KIND_LITLEN,
+                                      kLitlenBits, 15, 0, L.hdr.sorted_syms, &L.litlen_tablebits,
+                                      L.hdr.len_counts, L.hdr.offsets);
+    WAVE_SYNC();
+    ok = ok && build_decode_table_wave(L.tab, 0, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits,
+                                       15, L.litlen_tablebits, L.hdr.sorted_syms, nullptr, L.hdr.len_counts,
+                                       L.hdr.offsets);
     if (threadIdx.x == 0) {
         if (!ok) {
             L.status = RSX_BAD_DATA;
@@ -638,8 +625,9 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
 // ---- the symbol decoder ------------------------------------------------------------
 // Each lane runs a small state machine whose every step is ONE table lookup: a
 // litlen root entry, an offset root entry or a subtable entry.  A literal takes one
-// step, a match two (length, distance), long codes one more.  Lanes in different
-// states execute the same instructions (selects, no data-dependent branches), so a
+// step, a match two (length, distance), long codes one more.  The entry itself says
+// which table the next lookup uses, so the step has no state-dependent selects beyond
+// "pointer or not", and lanes in different states execute the same instructions: a
 // wave that holds literals, match halves and subtable hops at once does not diverge.
 //
 // Bit buffer: 64 bits per lane, refilled 32 bits at a time from the staged window;
@@ -653,8 +641,8 @@ struct Decoder {
     uint32_t next2;  // win[wnext + 1], so that a refill never waits for its load
     uint32_t b;      // window bit position of the next unread bit
     uint32_t tok;    // window bit position where the current token starts
-    uint32_t pend;   // match length waiting for its distance (0 = litlen phase)
-    uint32_t tbase;  // table index base of the next lookup (relative to litlen[0])
+    uint32_t pend;   // value of the last entry that was not a pointer: at a distance, the match length
+    uint32_t tbase;  // byte offset of the table of the next lookup
     uint32_t tmask;  // index mask of the next lookup
 
     __device__ inline void init(const StreamLds &L, uint32_t at, uint32_t litlen_mask)
@@ -667,22 +655,22 @@ struct Decoder {
         next2 = L.win[wnext + 1];
         b = tok = at;
         pend = 0;
-        tbase = 0;
+        tbase = 4 * kTabLitlen;
         tmask = litlen_mask;
     }
 };
 
 // result of one step
 struct StepOut {
-    uint32_t kind;   // 0 nothing finished (length read / subtable hop), 1 literal, 2 match, 3 end of block
-    uint32_t value;  // literal byte / match distance (the length is Decoder::pend before the step)
-    uint32_t len;    // match length when kind == 2
+    uint32_t kind;   // kTokNone (length read / subtable hop), kTokEob, kTokLit, kTokMatch
+    uint32_t value;  // literal byte / match distance
+    uint32_t len;    // match length when kind == kTokMatch
 };
 
 // kValues = false: only the token boundaries matter (literal bytes, lengths and distances are
-// not computed; a pending length is just "some")
+// not computed)
 template <bool kValues = true>
-__device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d, uint32_t litlen_mask)
+__device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
 {
     // refill: bc >= 32 afterwards
     const bool low = d.bc < 32;
@@ -693,34 +681,26 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d, uint32_t 
     d.next2 = L.win[d.wnext + 1];   // unconditional (no branch); first needed a refill later
 
     const uint32_t bits = (uint32_t)d.bb;
-    const uint32_t e = L.litlen[d.tbase + (bits & d.tmask)];
-    const bool in_off = d.pend != 0;
-    const bool is_ptr = (e & kSubtable) != 0;
-    const bool is_lit = (e & kLiteral) != 0;
-    const bool is_eob = !is_ptr && (e & kEndOfBlock) != 0;
-    const uint32_t total_bits = e & 0xFF, clen = (e >> 8) & 0xFF;
-    // a pointer consumes the root bits (its low byte); a final entry code + extra bits
-    const uint32_t value =
-        kValues ? ((e >> 16) & 0x7FFF) + ((bits >> clen) & ((1u << (total_bits - clen)) - 1)) : 1u;
+    const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.tab) + d.tbase +
+                                                          ((bits & d.tmask) << 2));
+    const uint32_t total_bits = e & 31, clen = (e >> 5) & 15;
+    const uint32_t field = (e >> 16) & 0x7FFF;
+    const bool is_ptr = (int32_t)e < 0;
+    // a pointer consumes the root index and has no extra bits; a final entry codeword + extra bits
+    const uint32_t value = kValues ? field + __builtin_amdgcn_ubfe(bits >> clen, 0u, total_bits - clen) : 0u;
     d.bb >>= total_bits;
     d.bc -= total_bits;
     d.b += total_bits;
 
     StepOut o;
-    const bool fin_off = !is_ptr && in_off;
-    const bool fin_lit = !is_ptr && !in_off && is_lit;
-    const bool fin_len = !is_ptr && !in_off && !is_lit && !is_eob;
-    o.kind = fin_off ? 2u : fin_lit ? 1u : (is_eob && !in_off) ? 3u : 0u;
+    o.kind = __builtin_amdgcn_ubfe(e, 9u, 2u);
     o.value = value;
     o.len = d.pend;
-    // next state
-    const uint32_t base_now = in_off ? (uint32_t)kLitlenEnough : 0u;
-    const uint32_t npend = fin_len ? value : (is_ptr ? d.pend : 0u);
-    const bool next_off = npend != 0;
-    d.tbase = is_ptr ? base_now + ((e >> 16) & 0x3FFF) : (next_off ? (uint32_t)kLitlenEnough : 0u);
-    d.tmask = is_ptr ? (1u << ((e >> 8) & 0x3F)) - 1 : (next_off ? (1u << kOffsetBits) - 1 : litlen_mask);
-    d.pend = npend;
-    d.tok = (fin_off || fin_lit) ? d.b : d.tok;
+    // next state, from the entry
+    d.tbase = is_ptr ? field : (e & kEntNextLit);
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(d.tmask) : "v"(__builtin_amdgcn_ubfe(e, 12u, 4u)));
+    if (kValues) d.pend = is_ptr ? d.pend : value;
+    d.tok = o.kind >= kTokLit ? d.b : d.tok;
     return o;
 }
 
@@ -747,11 +727,11 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
     bool running = d.b < bound;
     while (running) {
         const uint32_t t0 = d.tok;
-        const StepOut o = decoder_step(L, d, litlen_mask);
+        const StepOut o = decoder_step(L, d);
         const bool over = d.b > end32;            // ran past the body: stop at the token start
-        const bool eob = !over && o.kind == 3;
-        r.bytes += over ? 0u : o.kind == 2 ? o.len : (o.kind == 1 ? 1u : 0u);
-        r.nm += (!over && o.kind == 2) ? 1u : 0u;
+        const bool eob = !over && o.kind == kTokEob;
+        r.bytes += over ? 0u : o.kind == kTokMatch ? o.len : (o.kind == kTokLit ? 1u : 0u);
+        r.nm += (!over && o.kind == kTokMatch) ? 1u : 0u;
         r.exit = over ? (t0 | kExitStop) : eob ? (d.b | kExitEob) : d.b;
         running = !over && !eob && (d.tok != d.b || d.b < bound);
     }
@@ -770,8 +750,8 @@ __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_
     bool running = d.b < lo;
     uint32_t guess = lo;
     while (running) {
-        const StepOut o = decoder_step<false>(L, d, litlen_mask);
-        const bool stop = d.b > end32 || o.kind == 3;   // nothing to learn from here on
+        const StepOut o = decoder_step<false>(L, d);
+        const bool stop = d.b > end32 || o.kind == kTokEob;   // nothing to learn from here on
         guess = (!stop && d.tok == d.b && d.b >= lo) ? d.b : guess;
         running = !stop && (d.tok != d.b || d.b < lo);
     }
@@ -934,9 +914,10 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         d.init(L, start, litlen_mask);
         bool running = d.b < bound;
         while (running) {
-            const StepOut o = decoder_step(L, d, litlen_mask);
+            const StepOut o = decoder_step(L, d);
             const bool over = d.b > end32;
-            const bool lit = !over && o.kind == 1, mat = !over && o.kind == 2, eob = !over && o.kind == 3;
+            const bool lit = !over && o.kind == kTokLit, mat = !over && o.kind == kTokMatch;
+            const bool eob = !over && o.kind == kTokEob;
             const bool no_room = (lit && op >= cap) || (mat && (op > cap || o.len > cap - op));
             const bool too_far = mat && o.value > op;
             const int e = over ? RSX_SHORT_INPUT : too_far ? RSX_BAD_DATA : no_room ? RSX_INSUFFICIENT_SPACE : -1;

@@ -202,15 +202,15 @@ class Engine:
 
 
 _DEFAULT = {}
+_DEFAULT_LOCK = threading.Lock()   # not _LOCK: Engine() loads the library under that one
 
 
 def default_engine(device=0):
     """Process-wide engine per device, created lazily like the reference's
     OnceLock<Option<CudaBatchCompressor>> (src/batch.rs:7-8, :23-27)."""
-    with _LOCK:
-        pass
-    e = _DEFAULT.get(device)
-    if e is None:
-        e = Engine(device)
-        _DEFAULT[device] = e
-    return e
+    with _DEFAULT_LOCK:
+        e = _DEFAULT.get(device)
+        if e is None:
+            e = Engine(device)
+            _DEFAULT[device] = e
+        return e
