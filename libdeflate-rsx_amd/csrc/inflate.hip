@@ -630,15 +630,12 @@ __device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64
 // "pointer or not", and lanes in different states execute the same instructions: a
 // wave that holds literals, match halves and subtable hops at once does not diverge.
 //
-// Bit buffer: 64 bits per lane, refilled 32 bits at a time from the staged window;
-// the next two window dwords are always already loaded, so a refill adds no LDS round
-// trip to the step-to-step dependency chain.
+// Bit window: three consecutive dwords of the staged input per lane (the two that hold the
+// next 32 bits and the one behind them, loaded a step ahead), so that a step gets its bits with
+// one funnel shift and the LDS round trip of the refill is off the step-to-step dependency chain.
 struct Decoder {
-    uint64_t bb;     // unread bits, LSB first
-    uint32_t bc;     // valid bits in bb
-    uint32_t wnext;  // index of the prefetched window dword
-    uint32_t nextw;  // win[wnext]
-    uint32_t next2;  // win[wnext + 1], so that a refill never waits for its load
+    uint32_t w0, w1; // win[b >> 5], win[(b >> 5) + 1]
+    uint32_t w2;     // win[(b >> 5) + 2]
     uint32_t b;      // window bit position of the next unread bit
     uint32_t tok;    // window bit position where the current token starts
     uint32_t pend;   // value of the last entry that was not a pointer: at a distance, the match length
@@ -648,11 +645,9 @@ struct Decoder {
     __device__ inline void init(const StreamLds &L, uint32_t at, uint32_t litlen_mask)
     {
         const uint32_t w = at >> 5;
-        bb = (((uint64_t)L.win[w + 1] << 32) | L.win[w]) >> (at & 31);
-        bc = 64 - (at & 31);
-        wnext = w + 2;
-        nextw = L.win[wnext];
-        next2 = L.win[wnext + 1];
+        w0 = L.win[w];
+        w1 = L.win[w + 1];
+        w2 = L.win[w + 2];
         b = tok = at;
         pend = 0;
         tbase = 4 * kTabLitlen;
@@ -672,15 +667,7 @@ struct StepOut {
 template <bool kValues = true>
 __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
 {
-    // refill: bc >= 32 afterwards
-    const bool low = d.bc < 32;
-    d.bb |= low ? (uint64_t)d.nextw << d.bc : 0ull;
-    d.bc += low ? 32u : 0u;
-    d.wnext += low ? 1u : 0u;
-    d.nextw = low ? d.next2 : d.nextw;
-    d.next2 = L.win[d.wnext + 1];   // unconditional (no branch); first needed a refill later
-
-    const uint32_t bits = (uint32_t)d.bb;
+    const uint32_t bits = __builtin_amdgcn_alignbit(d.w1, d.w0, d.b);   // 32 bits from bit b on
     const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.tab) + d.tbase +
                                                           ((bits & d.tmask) << 2));
     const uint32_t total_bits = e & 31, clen = (e >> 5) & 15;
@@ -688,9 +675,13 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
     const bool is_ptr = (int32_t)e < 0;
     // a pointer consumes the root index and has no extra bits; a final entry codeword + extra bits
     const uint32_t value = kValues ? field + __builtin_amdgcn_ubfe(bits >> clen, 0u, total_bits - clen) : 0u;
-    d.bb >>= total_bits;
-    d.bc -= total_bits;
-    d.b += total_bits;
+    // consume: a step takes at most 28 bits, so the window moves by at most one dword
+    const uint32_t nb = d.b + total_bits;
+    const bool crossed = ((nb ^ d.b) & 32u) != 0;
+    d.w0 = crossed ? d.w1 : d.w0;
+    d.w1 = crossed ? d.w2 : d.w1;
+    d.w2 = L.win[(nb >> 5) + 2];   // unconditional (no branch); first needed after the next crossing
+    d.b = nb;
 
     StepOut o;
     o.kind = __builtin_amdgcn_ubfe(e, 9u, 2u);
@@ -740,7 +731,9 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
 
 // A better first guess for a sub-sequence: start kWarmBits in front of it and take the
 // first token boundary at or behind `lo`.  Huffman streams re-synchronise, so after a
-// stretch of warm-up the decoder is often on real token boundaries already.
+// stretch of warm-up the decoder is often on real token boundaries already.  An end-of-block
+// code does not stop the warm-up: when it is real, the lanes behind it are not part of this
+// round anyway, and when it is not, decoding on may still find the boundaries.
 __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_t lo, int64_t end_b,
                                       uint32_t litlen_mask)
 {
@@ -748,14 +741,13 @@ __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_
     d.init(L, from, litlen_mask);
     const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
     bool running = d.b < lo;
-    uint32_t guess = lo;
-    while (running) {
+    bool found = false;
+    while (running) {   // every step consumes at least one bit
         const StepOut o = decoder_step<false>(L, d);
-        const bool stop = d.b > end32 || o.kind == kTokEob;   // nothing to learn from here on
-        guess = (!stop && d.tok == d.b && d.b >= lo) ? d.b : guess;
-        running = !stop && (d.tok != d.b || d.b < lo);
+        found = o.kind >= kTokLit && d.b >= lo;   // a token ends at or behind lo
+        running = !found && d.b <= end32;
     }
-    return guess;
+    return (found && d.b <= end32) ? d.b : lo;
 }
 
 // exclusive prefix sums of two 32-bit values over the workgroup
