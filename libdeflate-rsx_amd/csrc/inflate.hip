@@ -637,7 +637,6 @@ struct Decoder {
     uint32_t w0, w1; // win[b >> 5], win[(b >> 5) + 1]
     uint32_t w2;     // win[(b >> 5) + 2]
     uint32_t b;      // window bit position of the next unread bit
-    uint32_t tok;    // window bit position where the current token starts
     uint32_t pend;   // value of the last entry that was not a pointer: at a distance, the match length
     uint32_t tbase;  // byte offset of the table of the next lookup
     uint32_t tmask;  // index mask of the next lookup
@@ -648,7 +647,7 @@ struct Decoder {
         w0 = L.win[w];
         w1 = L.win[w + 1];
         w2 = L.win[w + 2];
-        b = tok = at;
+        b = at;
         pend = 0;
         tbase = 4 * kTabLitlen;
         tmask = litlen_mask;
@@ -660,6 +659,7 @@ struct StepOut {
     uint32_t kind;   // kTokNone (length read / subtable hop), kTokEob, kTokLit, kTokMatch
     uint32_t value;  // literal byte / match distance
     uint32_t len;    // match length when kind == kTokMatch
+    uint32_t entry;  // the table entry itself
 };
 
 // kValues = false: only the token boundaries matter (literal bytes, lengths and distances are
@@ -680,18 +680,21 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
     const bool crossed = ((nb ^ d.b) & 32u) != 0;
     d.w0 = crossed ? d.w1 : d.w0;
     d.w1 = crossed ? d.w2 : d.w1;
-    d.w2 = L.win[(nb >> 5) + 2];   // unconditional (no branch); first needed after the next crossing
+    // win[(nb >> 5) + 2], as a masked byte offset so that the constant part folds into the load;
+    // unconditional (no branch); first needed after the next crossing
+    d.w2 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.win) + 8 +
+                                               ((nb >> 3) & 0x1FFCu));
     d.b = nb;
 
     StepOut o;
     o.kind = __builtin_amdgcn_ubfe(e, 9u, 2u);
     o.value = value;
     o.len = d.pend;
+    o.entry = e;
     // next state, from the entry
     d.tbase = is_ptr ? field : (e & kEntNextLit);
     asm("v_bfm_b32 %0, %1, 0" : "=v"(d.tmask) : "v"(__builtin_amdgcn_ubfe(e, 12u, 4u)));
     if (kValues) d.pend = is_ptr ? d.pend : value;
-    d.tok = o.kind >= kTokLit ? d.b : d.tok;
     return o;
 }
 
@@ -708,24 +711,34 @@ struct Scan {
 __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bound, int64_t end_b,
                                  uint32_t litlen_mask)
 {
-    Scan r{start, 0, 0};
     Decoder d;
     d.init(L, start, litlen_mask);
     // window bit positions are far below 2^31: compare in 32 bits
     const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
-    // a token is in flight while tok != b (length read, subtable hop).  One exit test per
-    // step; everything else is selects.
-    bool running = d.b < bound;
+    // One exit test per step; everything else is selects.  A step that runs past the body ends
+    // the loop, so what it added is taken back behind the loop instead of being guarded inside.
+    uint32_t tok = start;   // where the token in flight starts
+    uint32_t bytes = 0, nm = 0, inc = 0, kind = kTokNone;
+    bool is_match = false, over = false;
+    bool running = start < bound;
     while (running) {
-        const uint32_t t0 = d.tok;
         const StepOut o = decoder_step(L, d);
-        const bool over = d.b > end32;            // ran past the body: stop at the token start
-        const bool eob = !over && o.kind == kTokEob;
-        r.bytes += over ? 0u : o.kind == kTokMatch ? o.len : (o.kind == kTokLit ? 1u : 0u);
-        r.nm += (!over && o.kind == kTokMatch) ? 1u : 0u;
-        r.exit = over ? (t0 | kExitStop) : eob ? (d.b | kExitEob) : d.b;
-        running = !over && !eob && (d.tok != d.b || d.b < bound);
+        kind = o.kind;
+        over = d.b > end32;
+        is_match = kind == kTokMatch;
+        // bit 1 of the kind is 1 for a literal; end of block and unfinished tokens add 0
+        inc = is_match ? o.len : __builtin_amdgcn_ubfe(o.entry, 10u, 1u);
+        bytes += inc;
+        nm += is_match ? 1u : 0u;
+        const bool done = kind >= kTokLit;   // a token ended with this step
+        tok = (done && !over) ? d.b : tok;
+        running = !over && kind != kTokEob && (!done || d.b < bound);
     }
+    Scan r;
+    r.bytes = over ? bytes - inc : bytes;
+    r.nm = (over && is_match) ? nm - 1 : nm;
+    // ran past the body: stop at the token start
+    r.exit = over ? (tok | kExitStop) : kind == kTokEob ? (d.b | kExitEob) : d.b;
     return r;
 }
 
@@ -924,7 +937,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             op += bad ? 0u : lit ? 1u : mat ? o.len : 0u;
             mi += (mat && !bad) ? 1u : 0u;
             err = bad ? e : err;
-            running = !bad && !eob && (d.tok != d.b || d.b < bound);
+            running = !bad && !eob && (o.kind < kTokLit || d.b < bound);
         }
         if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
     }
