@@ -62,7 +62,7 @@ constexpr uint32_t kSubBits = 126;            // compressed bits per lane and ro
 constexpr uint32_t kRoundOut = 16384 - 16;    // output bytes per round
 constexpr uint32_t kMaxMatches = 1792;        // match queue entries per round
 #ifndef RSX_WARM_BITS
-#define RSX_WARM_BITS 200
+#define RSX_WARM_BITS 720
 #endif
 constexpr uint32_t kWarmBits = RSX_WARM_BITS;  // warm-up in front of a sub-sequence's first guess
 constexpr uint32_t kCopySub = 2048;           // output bytes resolved per copy step (u16 pointers fit in win)
@@ -162,8 +162,9 @@ struct MatchQueue {
     uint16_t dst[kMaxMatches];    // dst - round_start
 };
 struct __align__(16) StreamLds {
+    uint32_t win[kWinWords + 4];      // staged input (first: its LDS address is 0, so indexing it costs no add);
+                                      // reused as u16 source pointers by the copy phase
     uint8_t ring[kRing];
-    uint32_t win[kWinWords + 4];      // staged input; reused as u16 source pointers by the copy phase
     uint32_t tab[kTabLitlen + kLitlenEnough];   // decode tables: offset at index 0, litlen at kTabLitlen
     union {
         HeaderScratch hdr;
@@ -677,13 +678,11 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
     const uint32_t value = kValues ? field + __builtin_amdgcn_ubfe(bits >> clen, 0u, total_bits - clen) : 0u;
     // consume: a step takes at most 28 bits, so the window moves by at most one dword
     const uint32_t nb = d.b + total_bits;
-    const bool crossed = ((nb ^ d.b) & 32u) != 0;
+    const bool crossed = (nb & 31u) < total_bits;   // the low five bits wrapped
     d.w0 = crossed ? d.w1 : d.w0;
     d.w1 = crossed ? d.w2 : d.w1;
-    // win[(nb >> 5) + 2], as a masked byte offset so that the constant part folds into the load;
     // unconditional (no branch); first needed after the next crossing
-    d.w2 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.win) + 8 +
-                                               ((nb >> 3) & 0x1FFCu));
+    d.w2 = L.win[(nb >> 5) + 2];
     d.b = nb;
 
     StepOut o;
