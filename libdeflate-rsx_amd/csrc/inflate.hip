@@ -972,8 +972,15 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     // positions less than kRing in front of round_end are still in the ring once the round is complete
     const int tid = threadIdx.x;
     uint16_t *ptr = reinterpret_cast<uint16_t *>(L.win);
-    constexpr uint32_t kSelf = 0xFFFF;
-    constexpr uint32_t kBack = 32768;   // pointer value v refers to position sub_start - kBack + v
+    // A pointer is the source position minus sub_start, modulo 2^16: [0, kCopySub) points into the
+    // step (and may still move), [kLanded, kLanded + kCopySub) into the step at a byte known to be a
+    // literal, [2^16 - 32768 - kCopySub, 2^16) in front of the step.  kSelf (a literal: nothing to
+    // copy) lies in none of these ranges.
+    constexpr uint32_t kSelf = 0x6000;
+    constexpr uint32_t kLanded = 0x4000;
+    constexpr uint32_t kFront = 0x10000 - 32768 - kCopySub;   // smallest pointer to a byte in front of the step
+    static_assert(kLanded >= kCopySub && kLanded + kCopySub <= kSelf && kSelf < kFront, "pointer ranges are disjoint");
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
     if (tid == 0) ptr[kCopySub] = (uint16_t)kSelf;   // the spare slot (a pad word of the window buffer)
     WG_SYNC();
@@ -985,7 +992,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
         static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
-        reinterpret_cast<uint4 *>(ptr)[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        reinterpret_cast<uint4 *>(ptr)[tid] = make_uint4(kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u);
         WG_SYNC();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
         // The lane that sees the last match ending inside this step publishes the next
@@ -1012,20 +1019,22 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             }
             const uint32_t from = dst > sub_start ? dst : sub_start;
             const uint32_t to = dst + len < sub_end ? dst + len : sub_end;
-            // source position p - dist, encoded relative to sub_start - kBack
-            const uint32_t bias = kBack - dist - sub_start;
-            // four pointers per store: consecutive 16-bit values packed by hand (they stay below
-            // 2^16, so the pairs never carry into each other)
+            // four pointers per store: consecutive 16-bit values packed by hand; the source may run
+            // from in front of the step into it (0xFFFF -> 0), so the halves are added as 16-bit lanes
             {
                 uint32_t at = from - sub_start, left = to - from;
-                const uint32_t first = (from + bias) & 0xFFFF;
-                uint32_t lo = first | (first + 1) << 16, hi = (first + 2) | (first + 3) << 16;
-                for (; left >= 8; left -= 8, at += 8, lo += 0x00080008u, hi += 0x00080008u)
+                const uint32_t first = from - dist - sub_start;   // (mod 2^16)
+                auto pk = [](uint32_t a, uint32_t b) { return (a & 0xFFFF) | b << 16; };
+                auto add2 = [](uint32_t x, uint32_t inc) {
+                    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, x) + __builtin_bit_cast(u16x2, inc)));
+                };
+                uint32_t lo = pk(first, first + 1), hi = pk(first + 2, first + 3);
+                for (; left >= 8; left -= 8, at += 8, lo = add2(lo, 0x00080008u), hi = add2(hi, 0x00080008u))
                     *reinterpret_cast<uint4 *>(ptr + at) =
-                        make_uint4(lo, hi, lo + 0x00040004u, hi + 0x00040004u);   // (2-byte aligned)
+                        make_uint4(lo, hi, add2(lo, 0x00040004u), add2(hi, 0x00040004u));   // (2-byte aligned)
                 if (left >= 4) {
                     *reinterpret_cast<uint2 *>(ptr + at) = make_uint2(lo, hi);
-                    left -= 4, at += 4, lo += 0x00040004u, hi += 0x00040004u;
+                    left -= 4, at += 4, lo = add2(lo, 0x00040004u), hi = add2(hi, 0x00040004u);
                 }
                 if (left >= 1) ptr[at] = (uint16_t)lo;
                 if (left >= 2) ptr[at + 1] = (uint16_t)(lo >> 16);
@@ -1045,14 +1054,11 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; }
         // Pointer jumping: a pointer into this step that lands on a non-literal byte takes
         // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
-        // registers.  A pointer can still move while it points into the step (kBack <= v <
-        // kBack + kCopySub) and is not known to have landed on a literal; one that has is
-        // marked with kLanded (a bit no pointer into the step uses), in the table too, so
-        // whoever takes it over is settled at once.  The rounds are branch-free: settled bytes
+        // registers.  A pointer can still move while it points into the step (v < kCopySub)
+        // and is not known to have landed on a literal; one that has is marked with kLanded,
+        // in the table too, so whoever takes it over is settled at once.  The rounds are branch-free: settled bytes
         // read a spare slot behind the table and rewrite their own value.
         constexpr int kPer = kCopySub / kT;
-        constexpr uint32_t kLanded = 0x4000;
-        static_assert(kBack == 0x8000 && kCopySub <= kLanded, "kLanded is free in pointers into the step");
         uint32_t v[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; k++) v[k] = ptr[tid + k * kT];   // slots behind n hold kSelf
@@ -1062,18 +1068,17 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             // (all reads of a round are issued before the first dependent one is needed)
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                const uint32_t t = v[k] - kBack;
-                v2[k] = ptr[t < kCopySub ? t : kCopySub];
+                v2[k] = ptr[v[k] < kCopySub ? v[k] : kCopySub];
             }
             WG_SYNC();   // every read of this round precedes its writes
             bool moving = false;
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                const bool pending = v[k] - kBack < kCopySub;
+                const bool pending = v[k] < kCopySub;
                 const uint32_t nv = v2[k] == kSelf ? v[k] | kLanded : v2[k];
                 v[k] = pending ? nv : v[k];
                 ptr[tid + k * kT] = (uint16_t)v[k];
-                moving = moving || v[k] - kBack < kCopySub;
+                moving = moving || v[k] < kCopySub;
             }
             // one barrier publishes the new pointers and the waves' "still moving" flags
             const uint32_t wave_moving = __ballot(moving) != 0;
@@ -1093,7 +1098,8 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             for (int k = 0; k < kPer; k++) {
                 byte[k] = 0;
                 if (v[k] != kSelf) {
-                    const uint32_t sp = sub_start - kBack + (v[k] >= kBack ? v[k] & ~kLanded : v[k]);   // (32-bit positions)
+                    // (32-bit positions) in front of the step, or a literal of the step
+                    const uint32_t sp = sub_start + v[k] - (v[k] >= kFront ? 0x10000u : kLanded);
                     const bool far = round_end - sp > kRing;                   // has left the ring
                     // two separate reads: written as one conditional expression the compiler
                     // folds them into a single FLAT load whose address is either in LDS or in
