@@ -12,8 +12,8 @@
 //              load per lane;
 //   2. decode  all 256 lanes decode Huffman symbols at once.  The window is cut
 //              into 126-bit sub-sequences, lane i starts at a guessed bit position
-//              inside sub-sequence i (the end of a short warm-up decode in front
-//              of it) and decodes until it crosses into sub-sequence i+1.  Huffman
+//              inside sub-sequence i (the end of a warm-up decode over the 720 bits in
+//              front of it) and decodes until it crosses into sub-sequence i+1.  Huffman
 //              streams re-synchronise, so after a few passes of "restart where the
 //              previous lane really ended" every lane's start is the true one
 //              (lane 0 always is).  A prefix sum of the bytes each lane produces
