@@ -35,6 +35,7 @@
 #include "engine.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 // build with -DRSX_DEV_TIMERS=1 to get the finer in-kernel timers of RSX_INFLATE_STATS
@@ -752,14 +753,15 @@ __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_
     Decoder d;
     d.init(L, from, litlen_mask);
     const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
+    // Runs until a token (or a block) ends at or behind lo: every step consumes at least one bit and
+    // at most three steps in a row finish nothing (subtable hop, length, subtable hop), so the loop
+    // needs no other bound and stays inside the padded window.
     bool running = d.b < lo;
-    bool found = false;
-    while (running) {   // every step consumes at least one bit
+    while (running) {
         const StepOut o = decoder_step<false>(L, d);
-        found = o.kind >= kTokLit && d.b >= lo;   // a token ends at or behind lo
-        running = !found && d.b <= end32;
+        running = o.kind == kTokNone || d.b < lo;
     }
-    return (found && d.b <= end32) ? d.b : lo;
+    return d.b <= end32 ? d.b : lo;
 }
 
 // exclusive prefix sums of two 32-bit values over the workgroup
@@ -916,27 +918,37 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
         Decoder d;
         d.init(L, start, litlen_mask);
-        bool running = d.b < bound;
-        while (running) {
-            const StepOut o = decoder_step(L, d);
-            const bool over = d.b > end32;
-            const bool lit = !over && o.kind == kTokLit, mat = !over && o.kind == kTokMatch;
-            const bool eob = !over && o.kind == kTokEob;
-            const bool no_room = (lit && op >= cap) || (mat && (op > cap || o.len > cap - op));
-            const bool too_far = mat && o.value > op;
-            const int e = over ? RSX_SHORT_INPUT : too_far ? RSX_BAD_DATA : no_room ? RSX_INSUFFICIENT_SPACE : -1;
-            const bool bad = e >= 0;
-            if (lit && !bad) L.ring[(op + c.shift) & kRingMask] = (uint8_t)o.value;
-            if (mat && !bad) {
-                L.mq.dst[mi] = (uint16_t)(op - round_start);
-                L.ring[(op + c.shift) & kRingMask] = (uint8_t)(o.value - 1);
-                L.ring[(op + c.shift + 1) & kRingMask] = (uint8_t)((o.value - 1) >> 8);
-                L.ring[(op + c.shift + 2) & kRingMask] = (uint8_t)(o.len - 3);
+        auto emit_tokens = [&](auto room_checked) {
+            bool running = d.b < bound;
+            while (running) {
+                const StepOut o = decoder_step(L, d);
+                const bool over = d.b > end32;
+                const bool lit = !over && o.kind == kTokLit, mat = !over && o.kind == kTokMatch;
+                const bool eob = !over && o.kind == kTokEob;
+                const bool no_room =
+                    !decltype(room_checked)::value && ((lit && op >= cap) || (mat && (op > cap || o.len > cap - op)));
+                const bool too_far = mat && o.value > op;
+                const int e = over ? RSX_SHORT_INPUT : too_far ? RSX_BAD_DATA : no_room ? RSX_INSUFFICIENT_SPACE : -1;
+                const bool bad = e >= 0;
+                if (lit && !bad) L.ring[(op + c.shift) & kRingMask] = (uint8_t)o.value;
+                if (mat && !bad) {
+                    L.mq.dst[mi] = (uint16_t)(op - round_start);
+                    L.ring[(op + c.shift) & kRingMask] = (uint8_t)(o.value - 1);
+                    L.ring[(op + c.shift + 1) & kRingMask] = (uint8_t)((o.value - 1) >> 8);
+                    L.ring[(op + c.shift + 2) & kRingMask] = (uint8_t)(o.len - 3);
+                }
+                op += bad ? 0u : lit ? 1u : mat ? o.len : 0u;
+                mi += (mat && !bad) ? 1u : 0u;
+                err = bad ? e : err;
+                running = !bad && !eob && (o.kind < kTokLit || d.b < bound);
             }
-            op += bad ? 0u : lit ? 1u : mat ? o.len : 0u;
-            mi += (mat && !bad) ? 1u : 0u;
-            err = bad ? e : err;
-            running = !bad && !eob && (o.kind < kTokLit || d.b < bound);
+        };
+        // a lane whose tokens all end inside the output slot needs no per-token room check; the
+        // branch is taken by whole waves (every slot but a too small one)
+        if (__all(op + sc.bytes <= cap && op <= cap)) {
+            emit_tokens(std::true_type{});
+        } else {
+            emit_tokens(std::false_type{});
         }
         if (err >= 0) atomicMin(&L.emit_error, ((uint32_t)tid << 8) | (uint32_t)err);
     }
