@@ -708,6 +708,8 @@ struct Scan {
 // Decode tokens that start in [start, bound); end_b = first bit past the body
 // (window relative).  Bits past the body read as zero; a step that runs past the
 // body stops the chain at the start of its token (ShortInput when it is real).
+// kEndFar: the body ends behind everything a step can reach from this window, so no step runs past it
+template <bool kEndFar>
 __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bound, int64_t end_b,
                                  uint32_t litlen_mask)
 {
@@ -724,7 +726,7 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
     while (running) {
         const StepOut o = decoder_step(L, d);
         kind = o.kind;
-        over = d.b > end32;
+        over = !kEndFar && d.b > end32;
         is_match = kind == kTokMatch;
         // bit 1 of the kind is 1 for a literal; end of block and unfinished tokens add 0
         inc = is_match ? o.len : __builtin_amdgcn_ubfe(o.entry, 10u, 1u);
@@ -803,6 +805,8 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     const int64_t end_b = (int64_t)(c.body_len * 8) - win_bit0;  // first bit past the body
     const uint32_t litlen_mask = (1u << L.litlen_tablebits) - 1;
     const uint32_t round_start = L.round_start_lo;
+    // (uniform) the usual case: the body does not end in this window, nor within a token of its limit
+    const bool end_far = end_b > (int64_t)kWinLimitBits + 64;
     // lane i owns tokens that start in [b0 + i*S, b0 + (i+1)*S), clipped to the window
     const uint32_t lo = b0 + tid * kSubBits;
     uint32_t bound = lo + kSubBits;
@@ -826,7 +830,8 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     if (start >= bound) {
         sc = Scan{start, 0, 0};   // nothing starts here (window exhausted)
     } else {
-        sc = scan_span(L, start, bound, end_b, litlen_mask);
+        sc = end_far ? scan_span<true>(L, start, bound, end_b, litlen_mask)
+                     : scan_span<false>(L, start, bound, end_b, litlen_mask);
     }
     L.spec.lane_exit[tid] = sc.exit;
     L.spec.sub_bytes[tid] = (uint16_t)sc.bytes;
@@ -868,7 +873,8 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             if (st_i >= bound_i) {
                 r = Scan{st_i, 0, 0};   // the previous token overshoots this sub-sequence
             } else {
-                r = scan_span(L, st_i, bound_i, end_b, litlen_mask);
+                r = end_far ? scan_span<true>(L, st_i, bound_i, end_b, litlen_mask)
+                            : scan_span<false>(L, st_i, bound_i, end_b, litlen_mask);
             }
             L.spec.lane_exit[i] = r.exit;
             L.spec.sub_bytes[i] = (uint16_t)r.bytes;
@@ -918,11 +924,11 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
         Decoder d;
         d.init(L, start, litlen_mask);
-        auto emit_tokens = [&](auto room_checked) {
+        auto emit_tokens = [&](auto room_checked) {   // room_checked: neither the slot nor the body can end here
             bool running = d.b < bound;
             while (running) {
                 const StepOut o = decoder_step(L, d);
-                const bool over = d.b > end32;
+                const bool over = !decltype(room_checked)::value && d.b > end32;
                 const bool lit = !over && o.kind == kTokLit, mat = !over && o.kind == kTokMatch;
                 const bool eob = !over && o.kind == kTokEob;
                 const bool no_room =
@@ -943,9 +949,10 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
                 running = !bad && !eob && (o.kind < kTokLit || d.b < bound);
             }
         };
-        // a lane whose tokens all end inside the output slot needs no per-token room check; the
-        // branch is taken by whole waves (every slot but a too small one)
-        if (__all(op + sc.bytes <= cap && op <= cap)) {
+        // a lane whose tokens all end inside the output slot needs no per-token room check, and when
+        // the body ends far behind this window no step can run past it; the branch is taken by whole
+        // waves (everywhere but at the end of a stream and in a too small slot)
+        if (end_far && __all(op + sc.bytes <= cap && op <= cap)) {
             emit_tokens(std::true_type{});
         } else {
             emit_tokens(std::false_type{});
