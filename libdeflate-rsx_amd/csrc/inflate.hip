@@ -641,9 +641,9 @@ struct Decoder {
     uint32_t b;      // window bit position of the next unread bit
     uint32_t pend;   // value of the last entry that was not a pointer: at a distance, the match length
     uint32_t tbase;  // byte offset of the table of the next lookup
-    uint32_t tmask;  // index mask of the next lookup
+    uint32_t tbits;  // index width of the next lookup
 
-    __device__ inline void init(const StreamLds &L, uint32_t at, uint32_t litlen_mask)
+    __device__ inline void init(const StreamLds &L, uint32_t at, uint32_t litlen_bits)
     {
         const uint32_t w = at >> 5;
         w0 = L.win[w];
@@ -652,7 +652,7 @@ struct Decoder {
         b = at;
         pend = 0;
         tbase = 4 * kTabLitlen;
-        tmask = litlen_mask;
+        tbits = litlen_bits;
     }
 };
 
@@ -671,7 +671,7 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
 {
     const uint32_t bits = __builtin_amdgcn_alignbit(d.w1, d.w0, d.b);   // 32 bits from bit b on
     const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.tab) + d.tbase +
-                                                          ((bits & d.tmask) << 2));
+                                                          (__builtin_amdgcn_ubfe(bits, 0u, d.tbits) << 2));
     const uint32_t total_bits = e & 31, clen = (e >> 5) & 15;
     const uint32_t field = (e >> 16) & 0x7FFF;
     const bool is_ptr = (int32_t)e < 0;
@@ -693,7 +693,7 @@ __device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
     o.entry = e;
     // next state, from the entry
     d.tbase = is_ptr ? field : (e & kEntNextLit);
-    asm("v_bfm_b32 %0, %1, 0" : "=v"(d.tmask) : "v"(__builtin_amdgcn_ubfe(e, 12u, 4u)));
+    d.tbits = __builtin_amdgcn_ubfe(e, 12u, 4u);
     if (kValues) d.pend = is_ptr ? d.pend : value;
     return o;
 }
@@ -711,10 +711,10 @@ struct Scan {
 // kEndFar: the body ends behind everything a step can reach from this window, so no step runs past it
 template <bool kEndFar>
 __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bound, int64_t end_b,
-                                 uint32_t litlen_mask)
+                                 uint32_t litlen_bits)
 {
     Decoder d;
-    d.init(L, start, litlen_mask);
+    d.init(L, start, litlen_bits);
     // window bit positions are far below 2^31: compare in 32 bits
     const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
     // One exit test per step; everything else is selects.  A step that runs past the body ends
@@ -750,10 +750,10 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
 // code does not stop the warm-up: when it is real, the lanes behind it are not part of this
 // round anyway, and when it is not, decoding on may still find the boundaries.
 __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_t lo, int64_t end_b,
-                                      uint32_t litlen_mask)
+                                      uint32_t litlen_bits)
 {
     Decoder d;
-    d.init(L, from, litlen_mask);
+    d.init(L, from, litlen_bits);
     const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
     // Runs until a token (or a block) ends at or behind lo: every step consumes at least one bit and
     // at most three steps in a row finish nothing (subtable hop, length, subtable hop), so the loop
@@ -803,7 +803,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     const int tid = threadIdx.x;
     const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
     const int64_t end_b = (int64_t)(c.body_len * 8) - win_bit0;  // first bit past the body
-    const uint32_t litlen_mask = (1u << L.litlen_tablebits) - 1;
+    const uint32_t litlen_bits = L.litlen_tablebits;
     const uint32_t round_start = L.round_start_lo;
     // (uniform) the usual case: the body does not end in this window, nor within a token of its limit
     const bool end_far = end_b > (int64_t)kWinLimitBits + 64;
@@ -824,14 +824,14 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     // lane 0 starts where the previous round ended; the others warm up in front of their
     // sub-sequence (a lane whose warm-up reaches back to b0 is exact as well)
     uint32_t guess = lo;
-    if (tid > 0 && lo < bound) guess = warm_start(L, lo - b0 > kWarmBits ? lo - kWarmBits : b0, lo, end_b, litlen_mask);
+    if (tid > 0 && lo < bound) guess = warm_start(L, lo - b0 > kWarmBits ? lo - kWarmBits : b0, lo, end_b, litlen_bits);
     uint32_t start = guess;
     Scan sc;
     if (start >= bound) {
         sc = Scan{start, 0, 0};   // nothing starts here (window exhausted)
     } else {
-        sc = end_far ? scan_span<true>(L, start, bound, end_b, litlen_mask)
-                     : scan_span<false>(L, start, bound, end_b, litlen_mask);
+        sc = end_far ? scan_span<true>(L, start, bound, end_b, litlen_bits)
+                     : scan_span<false>(L, start, bound, end_b, litlen_bits);
     }
     L.spec.lane_exit[tid] = sc.exit;
     L.spec.sub_bytes[tid] = (uint16_t)sc.bytes;
@@ -873,8 +873,8 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             if (st_i >= bound_i) {
                 r = Scan{st_i, 0, 0};   // the previous token overshoots this sub-sequence
             } else {
-                r = end_far ? scan_span<true>(L, st_i, bound_i, end_b, litlen_mask)
-                            : scan_span<false>(L, st_i, bound_i, end_b, litlen_mask);
+                r = end_far ? scan_span<true>(L, st_i, bound_i, end_b, litlen_bits)
+                            : scan_span<false>(L, st_i, bound_i, end_b, litlen_bits);
             }
             L.spec.lane_exit[i] = r.exit;
             L.spec.sub_bytes[i] = (uint16_t)r.bytes;
@@ -923,7 +923,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
         const uint32_t cap = (uint32_t)c.out_cap;
         const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
         Decoder d;
-        d.init(L, start, litlen_mask);
+        d.init(L, start, litlen_bits);
         auto emit_tokens = [&](auto room_checked) {   // room_checked: neither the slot nor the body can end here
             bool running = d.b < bound;
             while (running) {
