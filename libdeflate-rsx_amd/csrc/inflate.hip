@@ -1014,9 +1014,12 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
         reinterpret_cast<uint4 *>(ptr)[tid] = make_uint4(kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u);
         WG_SYNC();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
-        // The lane that sees the last match ending inside this step publishes the next
-        // step's mcur (matches do not overlap, so "ends inside" is monotone).
+        // The matches that end inside this step are a prefix of them (matches do not overlap);
+        // every wave counts its own, the next step starts behind their sum.  The first lane of a
+        // wave has the wave's smallest match in every turn of the loop, so it stays in the loop
+        // longest and its count is complete.
         auto info_len = [&](uint32_t dst) { return (uint32_t)L.ring[(dst + c.shift + 2) & kRingMask] + 3; };
+        uint32_t ended = 0;
         for (uint32_t m = mcur + tid; m < nm; m += kT) {
             const uint32_t dst = round_start + L.mq.dst[m];
             const bool carried = dst < sub_start;   // (only the first match of a step can be)
@@ -1030,7 +1033,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
                 len = info_len(dst);
             }
             const bool ends_here = dst + len <= sub_end;
-            if (m == mcur && !ends_here) L.scan_carry[0] = mcur;
+            ended += (uint32_t)__popcll(__ballot(ends_here));
             if (dst >= sub_end) break;
             if (!ends_here) {
                 span[((step + 1) & 1) * 2] = dist;
@@ -1059,17 +1062,11 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
                 if (left >= 2) ptr[at + 1] = (uint16_t)(lo >> 16);
                 if (left >= 3) ptr[at + 2] = (uint16_t)hi;
             }
-            if (ends_here) {
-                bool next_ends = false;
-                if (m + 1 < nm) {
-                    const uint32_t dst1 = round_start + L.mq.dst[m + 1];
-                    next_ends = dst1 + info_len(dst1) <= sub_end;
-                }
-                if (!next_ends) L.scan_carry[0] = m + 1;
-            }
         }
+        if ((tid & 63) == 0) L.scan_carry[tid >> 6] = ended;
         WG_SYNC();
-        mcur = L.scan_carry[0];
+#pragma unroll
+        for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; }
         // Pointer jumping: a pointer into this step that lands on a non-literal byte takes
         // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
