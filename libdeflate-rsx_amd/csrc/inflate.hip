@@ -1002,6 +1002,11 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
     if (tid == 0) ptr[kCopySub] = (uint16_t)kSelf;   // the spare slot (a pad word of the window buffer)
+    // every step starts from a table of kSelf; a step clears it for the next one as soon as its own
+    // pointers are in registers
+    static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
+    const uint4 all_self = make_uint4(kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u);
+    reinterpret_cast<uint4 *>(ptr)[tid] = all_self;
     WG_SYNC();
     // a match that runs from one step into the next: the second step finds its distance and
     // length here (its first bytes in the ring are data by then); slots alternate between steps
@@ -1010,9 +1015,6 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
     for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub, step++) {
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
-        static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
-        reinterpret_cast<uint4 *>(ptr)[tid] = make_uint4(kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u);
-        WG_SYNC();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
         // The matches that end inside this step are a prefix of them (matches do not overlap);
         // every wave counts its own, the next step starts behind their sum.  The first lane of a
@@ -1106,6 +1108,7 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
             if (!any_moving) break;
         }
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
+        reinterpret_cast<uint4 *>(ptr)[tid] = all_self;   // (nobody reads the table any more in this step)
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
         // bytes that have left the ring (read back from the output)
         {
