@@ -199,3 +199,37 @@ def test_matches_across_copy_step_boundaries(eng):
     datas.append((block[:2047]) * 100)
     streams = [zlib.compress(d, 9)[2:-4] for d in datas] + [o.compress(d, 6) for d in datas]
     check_against_oracle(eng, streams, [len(d) for d in datas] * 2, 0)
+
+
+def test_long_codewords_use_subtables(eng):
+    """Skewed symbol statistics give codewords up to 15 bits, longer than the root index of the litlen
+    table (10 bits) and of the offset table (8 bits): geometric byte distributions for the literals,
+    and copies from one favourite distance with rare copies from all the others for the offsets."""
+    rs = np.random.RandomState(4242)
+    datas = []
+    for ratio in (0.5, 0.62, 0.75):
+        p = ratio ** np.arange(256, dtype=np.float64)
+        p /= p.sum()
+        datas.append(rs.choice(256, size=200000, p=p).astype(np.uint8).tobytes())
+    for favourite in (5, 300, 20000):
+        out = bytearray(rs.randint(0, 256, size=33000, dtype=np.uint8).tobytes())
+        while len(out) < 400000:
+            rare = rs.randint(0, 400) == 0
+            dist = int(rs.randint(1, 32768)) if rare else favourite
+            n = int(rs.randint(3, 7))
+            start = len(out) - dist
+            for k in range(n):
+                out.append(out[start + k])
+            if rs.randint(0, 3) == 0:
+                out.append(int(rs.randint(0, 256)))
+        datas.append(bytes(out))
+    streams, caps = [], []
+    for d in datas:
+        for lvl in (1, 6, 9):
+            streams.append(zlib.compress(d, lvl)[2:-4])
+            caps.append(len(d))
+        c = o.compress(d, 9)
+        if c is not None:
+            streams.append(c)
+            caps.append(len(d))
+    check_against_oracle(eng, streams, caps, 0)
