@@ -601,6 +601,28 @@ __device__ inline uint64_t load_le64(const uint8_t *p)
     return v;
 }
 
+// Index of the first non-zero byte of the 20 bytes x0..x4 (little endian), 20 if there is none.
+__device__ inline uint32_t first_diff_byte(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4)
+{
+    // v_ffbl_b32 gives 0xFFFFFFFF for zero; the clamped adds keep that value
+    uint32_t f0, f1, f2, f3, f4;
+    asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(x0));
+    asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(x1));
+    asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(x2));
+    asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(x3));
+    asm("v_ffbl_b32 %0, %1" : "=v"(f4) : "v"(x4));
+    asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(f1) : "v"(f1));
+    asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(f2) : "v"(f2));
+    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(f3) : "v"(f3), "s"(96u));    // (not inline constants)
+    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(f4) : "v"(f4), "s"(128u));
+    uint32_t bit = f0 < f1 ? f0 : f1;
+    bit = bit < f2 ? bit : f2;
+    uint32_t bit2 = f3 < f4 ? f3 : f4;
+    bit = bit < bit2 ? bit : bit2;
+    const uint32_t byte = bit >> 3;
+    return byte < 20 ? byte : 20;
+}
+
 // length of the common prefix of a and b, at most max_len (a < b, both inside the chunk)
 __device__ inline uint32_t match_length(const uint8_t *a, const uint8_t *b, uint32_t max_len)
 {
@@ -935,9 +957,10 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 link = L.prev[cand & (kWindow - 1)];
                 const uint32_t x4 = load_le32(m) ^ src4;
                 const uint64_t xa = load_le64(m + 4) ^ src_a, xb = load_le64(m + 12) ^ src_b;
-                const uint32_t la = xa ? 4 + ((uint32_t)(__ffsll((long long)xa) - 1) >> 3) : 12;
-                const uint32_t lb = xb ? 12 + ((uint32_t)(__ffsll((long long)xb) - 1) >> 3) : 20;
-                uint32_t l = x4 ? ((x4 & 0xFFFFFF) ? 0u : 3u) : (xa ? la : lb);
+                // first differing bit among the 160: per dword "find first one" (all ones when the
+                // dword is equal) plus the dword's bit offset with a saturating add, then the minimum
+                uint32_t l = first_diff_byte(x4, (uint32_t)xa, (uint32_t)(xa >> 32), (uint32_t)xb, (uint32_t)(xb >> 32));
+                l = l < 3 ? 0u : l;   // (matchfinder.rs:835-853: nothing shorter than three bytes counts)
                 if (l == 20 && max_len > 20) l = 20 + match_length(m + 20, src + 20, max_len - 20);
                 l = l < max_len ? l : max_len;         // bytes past the chunk end do not count
                 const bool better = l > best_len;
