@@ -943,8 +943,9 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
                     L.ring[(op + c.shift + 1) & kRingMask] = (uint8_t)((o.value - 1) >> 8);
                     L.ring[(op + c.shift + 2) & kRingMask] = (uint8_t)(o.len - 3);
                 }
-                op += bad ? 0u : lit ? 1u : mat ? o.len : 0u;
-                mi += (mat && !bad) ? 1u : 0u;
+                // (a failing token ends the loop: what it adds here is never used)
+                op += mat ? o.len : lit ? 1u : 0u;
+                mi += mat ? 1u : 0u;
                 err = bad ? e : err;
                 running = !bad && !eob && (o.kind < kTokLit || d.b < bound);
             }
