@@ -25,7 +25,11 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr uint32_t kSeg = 32768;  // bytes per workgroup
+constexpr uint32_t kSeg = 32768;  // bytes per partial result
+#ifndef RSX_CRC_SEGS_PER_WG
+#define RSX_CRC_SEGS_PER_WG 4
+#endif
+constexpr uint32_t kSegsPerWg = RSX_CRC_SEGS_PER_WG;  // segments a workgroup reduces in turn (the tables are loaded once)
 constexpr uint32_t kPoly = 0xEDB88320u;
 constexpr uint32_t kAdlerMod = 65521u;
 
@@ -78,16 +82,16 @@ __device__ inline uint64_t item_len(const uint64_t *starts, const uint64_t *lens
 
 __device__ inline SegInfo locate(const uint8_t *in, const uint64_t *starts, const uint64_t *lens,
                                  uint32_t n, const uint32_t *seg_start, uint32_t segs_per_item,
-                                 uint32_t *item_ret)
+                                 uint32_t slot, uint32_t *item_ret)
 {
     SegInfo s{};
     uint32_t item, seg;
     if (seg_start == nullptr) {
-        item = blockIdx.x / segs_per_item;
-        seg = blockIdx.x % segs_per_item;
+        item = slot / segs_per_item;
+        seg = slot % segs_per_item;
         if (item >= n) return s;
     } else {
-        uint32_t g = blockIdx.x;
+        uint32_t g = slot;
         if (g >= seg_start[n]) return s;
         uint32_t lo = 0, hi = n;  // find item with seg_start[item] <= g < seg_start[item+1]
         while (hi - lo > 1) {
@@ -123,7 +127,7 @@ __device__ inline uint64_t wg_reduce_add(uint64_t v, uint64_t *lds)
     return lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-// One workgroup = one segment.  partial[slot] receives
+// One workgroup reduces kSegsPerWg segments (slots), one after the other.  partial[slot] receives
 //   CRC-32 : {raw register of the segment from a zero start, 0}
 //   Adler-32: {S1 mod 65521, sum (L - i) d_i mod 65521}
 template <int KIND>
@@ -138,10 +142,11 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
     if (KIND == RSX_CHECKSUM_CRC32) {
         for (int i = tid; i < 2048; i += kThreads) tab[i] = tables[i];
     }
-    uint32_t item;
-    SegInfo s = locate(in, starts, lens, n, seg_start, segs_per_item, &item);
     WG_SYNC();
-    if (!s.valid) return;  // slot past the end of a short item: never read by the fold
+    for (uint32_t slot = blockIdx.x * kSegsPerWg; slot < (blockIdx.x + 1) * kSegsPerWg; slot++) {
+    uint32_t item;
+    SegInfo s = locate(in, starts, lens, n, seg_start, segs_per_item, slot, &item);
+    if (!s.valid) continue;  // slot past the end of a short item or of the batch: never read by the fold (uniform)
     const uint64_t seg_begin = (uint64_t)s.seg * kSeg;
     const uint32_t L = (uint32_t)((s.len - seg_begin) < kSeg ? (s.len - seg_begin) : kSeg);
     const uint8_t *p = s.base + seg_begin;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
             uint32_t from = full_units ? 0 : head;
             const uint8_t *t = grid + 16 * (size_t)full_units;
             for (uint32_t b = from; b < tail; b++) crc = (crc >> 8) ^ tab[(crc ^ t[b]) & 0xFF];
-            partial[blockIdx.x] = make_uint2(crc, 0);
+            partial[slot] = make_uint2(crc, 0);
         }
     } else {
         // weights: byte at grid offset g has data index i = g - head and weight (L - i)
@@ -210,8 +215,9 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
         if (tid == 0) {
             // sum (L - i) d_i = (L + head) * S1 - W
             uint64_t s2 = (uint64_t)(L + head) * S1 - W;
-            partial[blockIdx.x] = make_uint2((uint32_t)(S1 % kAdlerMod), (uint32_t)(s2 % kAdlerMod));
+            partial[slot] = make_uint2((uint32_t)(S1 % kAdlerMod), (uint32_t)(s2 % kAdlerMod));
         }
+    }
     }
 }
 
@@ -328,7 +334,7 @@ int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
     const uint64_t bound = seg_upper_bound(n, total_in);
     const uint64_t segs_per_item = (max_item + kSeg - 1) / kSeg;
     const bool uniform = segs_per_item * n <= 2 * bound && segs_per_item > 0;
-    uint64_t grid = uniform ? segs_per_item * n : bound;
+    uint64_t grid = ((uniform ? segs_per_item * n : bound) + kSegsPerWg - 1) / kSegsPerWg;
     if (grid == 0) grid = 1;
     if (grid > 0x7FFFFFFFull) {
         e->err = "checksum launch too large";
