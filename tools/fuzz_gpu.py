@@ -1,0 +1,127 @@
+"""Differential fuzz of the GPU inflater against the oracle (run on a GPU box from the repo root):
+python tools/fuzz_gpu.py [seconds] [first_seed].  Streams come from zlib with every strategy and level,
+from the oracle's compressor, and from damaged copies of both; every status code and every decoded byte
+must agree.  Prints one line per seed and stops at the first disagreement."""
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
+import corpus  # noqa: E402
+import oracle_lib as o  # noqa: E402
+import rsx_pkg  # noqa: E402
+
+WBITS = {0: -15, 1: 15, 2: 31}
+STRATEGIES = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+
+
+def make_data(rs):
+    kind = rs.randint(0, 7)
+    n = int(rs.choice([0, 1, 5, 300, 4000, 70000, 300000, 1 << 20]))
+    n = int(n * rs.uniform(0.5, 1.0)) if n > 10 else n
+    seed = int(rs.randint(0, 1 << 20))
+    if kind == 0:
+        return corpus.text(n, seed)
+    if kind == 1:
+        return corpus.mixed(n, seed)
+    if kind == 2:
+        return corpus.json_like(n, seed)
+    if kind == 3:
+        return bytes(n)
+    if kind == 4:
+        return corpus.periodic(int(rs.randint(1, 300)), n)
+    if kind == 5:
+        p = rs.uniform(0.4, 0.95) ** np.arange(256)
+        return rs.choice(256, size=n, p=p / p.sum()).astype(np.uint8).tobytes()
+    return rs.randint(0, 256, size=n, dtype=np.uint8).tobytes()
+
+
+def trailer_is_displaced(s, fmt):
+    """True when the DEFLATE data of a zlib / gzip stream does not end exactly in front of the trailer.
+    The reference looks for the trailer behind the bytes its bit buffer has loaded, which is the real place
+    only when nothing sits between the last block and the trailer; the engine looks behind the last block."""
+    try:
+        if fmt == 1:
+            body = s[2:-4]
+        else:
+            h, flg = 10, s[3]
+            if flg & 4:
+                h += 2 + (s[h] | s[h + 1] << 8)
+            for bit in (8, 16):
+                if flg & bit:
+                    h = s.index(b"\0", h) + 1
+            if flg & 2:
+                h += 2
+            body = s[h:-8]
+        do = zlib.decompressobj(-15)
+        do.decompress(body)
+        return do.eof and len(do.unused_data) > 0
+    except Exception:
+        return False
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    eng = rsx_pkg.load().default_engine()
+    t0 = time.time()
+    total = displaced = 0
+    while time.time() - t0 < budget:
+        rs = np.random.RandomState(seed)
+        fmt = int(rs.randint(0, 3))
+        streams, caps = [], []
+        for _ in range(24):
+            d = make_data(rs)
+            co = zlib.compressobj(int(rs.randint(0, 10)), zlib.DEFLATED, WBITS[fmt], int(rs.randint(1, 10)),
+                                  STRATEGIES[rs.randint(0, len(STRATEGIES))])
+            parts = []
+            step = max(1, len(d) // int(rs.randint(1, 6)))
+            for at in range(0, len(d), step):   # flushes make many (also empty and stored) blocks
+                parts.append(co.compress(d[at:at + step]))
+                if rs.randint(0, 2):
+                    parts.append(co.flush(int(rs.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK]))))
+            parts.append(co.flush())
+            good = [b"".join(parts)]
+            oc = o.compress(d, int(rs.choice([0, 1, 4, 6, 9, 12])), fmt)
+            if oc is not None:
+                good.append(oc)
+            for s in good:
+                streams.append(s)
+                caps.append(len(d) + int(rs.choice([0, 0, 0, 9, -1])) if len(d) else 0)
+                if len(s) > 1:
+                    b = bytearray(s)
+                    what = rs.randint(0, 3)
+                    if what == 0:
+                        b[rs.randint(0, len(b))] ^= 1 << rs.randint(0, 8)
+                    elif what == 1:
+                        b = b[:rs.randint(0, len(b))]
+                    else:
+                        at = rs.randint(0, len(b))
+                        b[at:] = rs.randint(0, 256, size=len(b) - at, dtype=np.uint8).tobytes()
+                    streams.append(bytes(b))
+                    caps.append(len(d))
+        caps = [max(0, c) for c in caps]
+        got, status = eng.batch_decompress(streams, caps, fmt)
+        for i, s in enumerate(streams):
+            r, _, want = o.decompress(s, caps[i], fmt)
+            if int(status[i]) != r or (r == o.SUCCESS and got[i] != want):
+                if fmt != 0 and trailer_is_displaced(s, fmt):
+                    displaced += 1   # the one documented divergence: where the trailer is looked for
+                    continue
+                print("MISMATCH seed %d item %d fmt %d: gpu %d oracle %d" % (seed, i, fmt, int(status[i]), r))
+                with open("gpurun_out/fuzz_fail_%d_%d.bin" % (seed, i), "wb") as f:
+                    f.write(s)
+                sys.exit(1)
+        total += len(streams)
+        print("seed %d ok (%d streams, fmt %d)" % (seed, len(streams), fmt), flush=True)
+        seed += 1
+    print("fuzz ok: %d streams, seeds up to %d, %d with a displaced trailer skipped" % (total, seed - 1, displaced))
+
+
+if __name__ == "__main__":
+    main()
