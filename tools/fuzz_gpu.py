@@ -1,5 +1,5 @@
 """Differential fuzz of the GPU inflater against the oracle (run on a GPU box from the repo root):
-python tools/fuzz_gpu.py [seconds] [first_seed].  Streams come from zlib with every strategy and level,
+python tools/fuzz_gpu.py [seconds] [first_seed] [compress].  Streams come from zlib with every strategy and level,
 from the oracle's compressor, and from damaged copies of both; every status code and every decoded byte
 must agree.  Prints one line per seed and stops at the first disagreement."""
 import os
@@ -65,10 +65,37 @@ def trailer_is_displaced(s, fmt):
         return False
 
 
+def fuzz_compress(eng, rsx, budget, seed):
+    """Every stream the GPU compressor emits (any level, container and size) must fit the bound and
+    inflate, with zlib, to its input."""
+    t0 = time.time()
+    total = 0
+    while time.time() - t0 < budget:
+        rs = np.random.RandomState(seed)
+        fmt, level = int(rs.randint(0, 3)), int(rs.randint(0, 13))
+        datas = [make_data(rs) for _ in range(16)]
+        comp, status = eng.batch_compress(datas, fmt, level)
+        for i, d in enumerate(datas):
+            ok = int(status[i]) == 0 and len(comp[i]) <= rsx.compress_bound(fmt, len(d))
+            ok = ok and zlib.decompress(comp[i], WBITS[fmt]) == d
+            if not ok:
+                print("COMPRESS MISMATCH seed %d item %d fmt %d level %d" % (seed, i, fmt, level))
+                with open("gpurun_out/fuzz_cfail_%d_%d.bin" % (seed, i), "wb") as f:
+                    f.write(d)
+                sys.exit(1)
+        total += len(datas)
+        print("seed %d ok (fmt %d level %d)" % (seed, fmt, level), flush=True)
+        seed += 1
+    print("compress fuzz ok: %d buffers, seeds up to %d" % (total, seed - 1))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    eng = rsx_pkg.load().default_engine()
+    rsx = rsx_pkg.load()
+    eng = rsx.default_engine()
+    if len(sys.argv) > 3 and sys.argv[3] == "compress":
+        return fuzz_compress(eng, rsx, budget, seed)
     t0 = time.time()
     total = displaced = 0
     while time.time() - t0 < budget:
