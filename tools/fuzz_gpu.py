@@ -65,12 +65,12 @@ def trailer_is_displaced(s, fmt):
         return False
 
 
-def fuzz_compress(eng, rsx, budget, seed):
+def fuzz_compress(eng, rsx, budget, seed, max_seeds=1 << 30):
     """Every stream the GPU compressor emits (any level, container and size) must fit the bound and
     inflate, with zlib, to its input."""
     t0 = time.time()
-    total = 0
-    while time.time() - t0 < budget:
+    total, last = 0, seed + max_seeds
+    while time.time() - t0 < budget and seed < last:
         rs = np.random.RandomState(seed)
         fmt, level = int(rs.randint(0, 3)), int(rs.randint(0, 13))
         datas = [make_data(rs) for _ in range(16)]
@@ -96,9 +96,14 @@ def main():
     eng = rsx.default_engine()
     if len(sys.argv) > 3 and sys.argv[3] == "compress":
         return fuzz_compress(eng, rsx, budget, seed)
+    return fuzz_inflate(eng, budget, seed)
+
+
+def fuzz_inflate(eng, budget, seed, max_seeds=1 << 30):
     t0 = time.time()
     total = displaced = 0
-    while time.time() - t0 < budget:
+    last = seed + max_seeds
+    while time.time() - t0 < budget and seed < last:
         rs = np.random.RandomState(seed)
         fmt = int(rs.randint(0, 3))
         streams, caps = [], []
