@@ -144,7 +144,8 @@ int rsx_adler32(rsx_engine *e, uint32_t adler, const uint8_t *data, size_t len, 
  * data already lives in HBM.  total_in = in_off[n] - in_off[0], max_item (the
  * largest item's input length) and, for decompress, total_out / max_out (sum
  * and maximum of the output slot sizes) are host-known scalars used to size
- * the launch and the workspace.  Items must be smaller than 4 GiB.  A max_item
+ * the launch and the workspace.  Items and output slots must be smaller than
+ * 4 GiB - 64 KiB (larger ones are refused with RSX_E_INVALID).  A max_item
  * smaller than the longest item costs compression, not safety: such items are
  * written as stored blocks (or report InsufficientSpace).
  */

@@ -1445,8 +1445,9 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                    const uint64_t *out_off, uint64_t *out_sizes, int32_t *status)
 {
     if (n == 0) return RSX_OK;
-    if (n > 0x7FFFFFFFull || max_out >= (1ull << 32)) {
-        e->err = "batch too large (items must be < 4 GiB, n < 2^31)";
+    // (output positions are 32-bit in the kernel, and a round adds up to 16 KiB before it is checked)
+    if (n > 0x7FFFFFFFull || max_out >= (1ull << 32) - (1ull << 16)) {
+        e->err = "batch too large (output slots must be < 4 GiB - 64 KiB, n < 2^31)";
         return RSX_E_INVALID;
     }
     uint64_t *body_end = static_cast<uint64_t *>(ws_take(e, n * sizeof(uint64_t)));
