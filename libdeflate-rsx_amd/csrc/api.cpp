@@ -4,13 +4,18 @@
 // D2H) around the *_device entry points.
 #include "engine.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
 int ws_reserve(rsx_engine *e, size_t bytes)
 {
     e->ws_used = 0;
+    e->arena = e->ws;
+    e->arena_size = e->ws_size;
     if (bytes <= e->ws_size) return RSX_OK;
+    e->arena = nullptr;
+    e->arena_size = 0;
     if (e->ws) {
         RSX_HIP(e, hipStreamSynchronize(e->stream));
         RSX_HIP(e, hipFree(e->ws));
@@ -24,15 +29,17 @@ int ws_reserve(rsx_engine *e, size_t bytes)
         return RSX_E_NOMEM;
     }
     e->ws_size = want;
+    e->arena = e->ws;
+    e->arena_size = want;
     return RSX_OK;
 }
 
 void *ws_take(rsx_engine *e, size_t bytes)
 {
     size_t at = align_up(e->ws_used, 256);
-    if (at + bytes > e->ws_size) return nullptr;
+    if (!e->arena || at + bytes > e->arena_size) return nullptr;
     e->ws_used = at + bytes;
-    return e->ws + at;
+    return e->arena + at;
 }
 
 namespace {
@@ -110,11 +117,16 @@ int rsx_engine_create(int device, void *stream, rsx_engine **out)
         }
         e->own_stream = true;
     }
+    hipDeviceProp_t prop;
     if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess ||
-        checksum_tables_create(e) != RSX_OK) {
+        checksum_tables_create(e) != RSX_OK ||
+        hipGetDeviceProperties(&prop, device) != hipSuccess) {
         rsx_engine_destroy(e);
         return RSX_E_DEVICE;
     }
+    e->num_cus = prop.multiProcessorCount;
+    e->inflate_stats = getenv("RSX_INFLATE_STATS") != nullptr;
+    e->inflate_split = getenv("RSX_INFLATE_FUSED") == nullptr && !e->inflate_stats;
     *out = e;
     return RSX_OK;
 }
@@ -177,7 +189,7 @@ int rsx_batch_checksum_device(rsx_engine *e, int kind, uint32_t init, const uint
     int r = ws_reserve(e, checksum_ws_bytes(n, total_in));
     if (r != RSX_OK) return r;
     time_begin(e);
-    r = checksum_launch(e, kind, init, in, in_off, nullptr, n, total_in, max_item, values);
+    r = checksum_launch(e, kind, init, in, in_off, nullptr, n, total_in, max_item, values, false);
     time_end(e);
     return r;
 }
@@ -193,10 +205,10 @@ int rsx_batch_decompress_device(rsx_engine *e, int format, const uint8_t *in,
     if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
-    int r = ws_reserve(e, inflate_ws_bytes(n, total_out));
+    int r = ws_reserve(e, inflate_ws_bytes(n, total_in, total_out, e->inflate_split));
     if (r != RSX_OK) return r;
     return inflate_launch(e, format, in, in_off, n, total_in, total_out, max_out, out, out_off,
-                          out_sizes, status);
+                          out_sizes, status, e->inflate_split);
 }
 
 int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_t *in,
@@ -214,7 +226,7 @@ int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_
     int r = ws_reserve(e, deflate_ws_bytes(n, total_in, max_item, level));
     if (r != RSX_OK) return r;
     return deflate_launch(e, format, level, in, in_off, n, total_in, max_item, out, out_off,
-                          out_sizes, status, RSX_FLUSH_FINISH);
+                          out_sizes, status, RSX_FLUSH_FINISH, false);
 }
 
 // ---- host-pointer entry points ------------------------------------------------
@@ -245,7 +257,7 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
     DeviceGuard g(e->device);
 
     size_t kernel_ws = op == 0   ? deflate_ws_bytes(n, si.total, si.max_item, level)
-                       : op == 1 ? inflate_ws_bytes(n, so.total)
+                       : op == 1 ? inflate_ws_bytes(n, si.total, so.total, e->inflate_split)
                                  : checksum_ws_bytes(n, si.total);
     size_t need = kernel_ws + align_up(si.total + 64, 256) + align_up(so.total + 64, 256) +
                   4 * align_up((n + 1) * sizeof(uint64_t), 256) + 2 * align_up(n * 4, 256) + 4096;
@@ -297,13 +309,13 @@ static int stage_and_run(rsx_engine *e, int op, int format, int level, int kind,
 
     if (op == 0)
         r = deflate_launch(e, format, level, s.d_in, s.d_in_off, n, si.total, si.max_item, s.d_out,
-                           s.d_out_off, s.d_sizes, s.d_status, kind /* compress: the flush mode */);
+                           s.d_out_off, s.d_sizes, s.d_status, kind /* compress: the flush mode */, true);
     else if (op == 1)
         r = inflate_launch(e, format, s.d_in, s.d_in_off, n, si.total, so.total, so.max_item,
-                           s.d_out, s.d_out_off, s.d_sizes, s.d_status);
+                           s.d_out, s.d_out_off, s.d_sizes, s.d_status, e->inflate_split);
     else
         r = checksum_launch(e, kind, init, s.d_in, s.d_in_off, nullptr, n, si.total, si.max_item,
-                            s.d_values);
+                            s.d_values, true);
     if (r != RSX_OK) return r;
 
     if (out_off) {

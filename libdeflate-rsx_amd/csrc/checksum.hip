@@ -227,7 +227,7 @@ __global__ void checksum_combine_kernel(const uint64_t *__restrict__ starts,
                                         const uint64_t *__restrict__ lens, uint32_t n,
                                         const uint32_t *__restrict__ seg_start,
                                         uint32_t segs_per_item, const uint32_t *__restrict__ tables,
-                                        const uint2 *__restrict__ partial, uint32_t init,
+                                        const uint2 *__restrict__ partial, uint64_t num_slots, uint32_t init,
                                         uint32_t *__restrict__ values)
 {
     uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,6 +235,11 @@ __global__ void checksum_combine_kernel(const uint64_t *__restrict__ starts,
     uint64_t len = item_len(starts, lens, item);
     uint32_t nseg = (uint32_t)((len + kSeg - 1) / kSeg);
     size_t first = seg_start ? seg_start[item] : (size_t)item * segs_per_item;
+    // the items are longer than the caller's total said: there are no partials for this one
+    if (first + nseg > num_slots || (!seg_start && nseg > segs_per_item)) {
+        values[item] = 0;
+        return;
+    }
     if (KIND == RSX_CHECKSUM_CRC32) {
         uint32_t reg = ~init;
         const uint32_t xseg = tables[kTabXSeg];
@@ -324,7 +329,7 @@ size_t checksum_ws_bytes(size_t n, uint64_t total_in)
 
 int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
                     const uint64_t *in_off, const uint64_t *lens, size_t n, uint64_t total_in,
-                    uint64_t max_item, uint32_t *values)
+                    uint64_t max_item, uint32_t *values, bool trusted_max)
 {
     if (n == 0) return RSX_OK;
     if (n > 0x7FFFFFFFull) {
@@ -333,7 +338,10 @@ int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
     }
     const uint64_t bound = seg_upper_bound(n, total_in);
     const uint64_t segs_per_item = (max_item + kSeg - 1) / kSeg;
-    const bool uniform = segs_per_item * n <= 2 * bound && segs_per_item > 0;
+    // Uniform mode gives every item ceil(max_item / kSeg) slots without looking at the lengths: an
+    // understated max_item would make the fold read a neighbour's partials, so it is only taken when
+    // this library computed max_item itself.
+    const bool uniform = trusted_max && segs_per_item * n <= 2 * bound && segs_per_item > 0;
     uint64_t grid = ((uniform ? segs_per_item * n : bound) + kSegsPerWg - 1) / kSegsPerWg;
     if (grid == 0) grid = 1;
     if (grid > 0x7FFFFFFFull) {
@@ -357,12 +365,12 @@ int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
         checksum_partial_kernel<RSX_CHECKSUM_CRC32><<<(uint32_t)grid, kThreads, 0, e->stream>>>(
             in, in_off, lens, (uint32_t)n, seg_arg, spi, e->d_crc_tables, partial);
         checksum_combine_kernel<RSX_CHECKSUM_CRC32><<<cgrid, 256, 0, e->stream>>>(
-            in_off, lens, (uint32_t)n, seg_arg, spi, e->d_crc_tables, partial, init, values);
+            in_off, lens, (uint32_t)n, seg_arg, spi, e->d_crc_tables, partial, grid * kSegsPerWg, init, values);
     } else {
         checksum_partial_kernel<RSX_CHECKSUM_ADLER32><<<(uint32_t)grid, kThreads, 0, e->stream>>>(
             in, in_off, lens, (uint32_t)n, seg_arg, spi, e->d_crc_tables, partial);
         checksum_combine_kernel<RSX_CHECKSUM_ADLER32><<<cgrid, 256, 0, e->stream>>>(
-            in_off, lens, (uint32_t)n, seg_arg, spi, e->d_crc_tables, partial, init, values);
+            in_off, lens, (uint32_t)n, seg_arg, spi, e->d_crc_tables, partial, grid * kSegsPerWg, init, values);
     }
     RSX_HIP(e, hipGetLastError());
     return RSX_OK;

@@ -1346,8 +1346,6 @@ __global__ __launch_bounds__(256) void deflate_gather_kernel(
     }
 }
 
-int g_num_cus = 0;
-
 uint64_t chunk_upper_bound(size_t n, uint64_t total_in) { return total_in / kChunk + n; }
 
 }  // namespace
@@ -1375,21 +1373,18 @@ size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int leve
 
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
                    size_t n, uint64_t total_in, uint64_t max_item, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, int flush)
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, int flush,
+                   bool trusted_max)
 {
     if (n == 0) return RSX_OK;
     if (n > 0x7FFFFFFFull || max_item >= (1ull << 32)) {
         e->err = "batch too large (items must be < 4 GiB, n < 2^31)";
         return RSX_E_INVALID;
     }
-    if (g_num_cus == 0) {
-        hipDeviceProp_t prop;
-        RSX_HIP(e, hipGetDeviceProperties(&prop, e->device));
-        g_num_cus = prop.multiProcessorCount;
-    }
+    const int num_cus = e->num_cus > 0 ? e->num_cus : 256;
     const uint64_t chunks = chunk_upper_bound(n, total_in);
     const uint64_t stride = scratch_stride(max_item);
-    uint32_t grid = (uint32_t)(chunks < (uint64_t)g_num_cus ? chunks : (uint64_t)g_num_cus);
+    uint32_t grid = (uint32_t)(chunks < (uint64_t)num_cus ? chunks : (uint64_t)num_cus);
     if (grid > 1024) grid = 1024;
     uint8_t *scratch = static_cast<uint8_t *>(ws_take(e, chunks * stride));
     uint32_t *chunk_size = static_cast<uint32_t *>(ws_take(e, (chunks + 1) * 4));
@@ -1438,7 +1433,7 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     if (format != RSX_FORMAT_DEFLATE) {
         int kind = format == RSX_FORMAT_GZIP ? RSX_CHECKSUM_CRC32 : RSX_CHECKSUM_ADLER32;
         int r = checksum_launch(e, kind, format == RSX_FORMAT_GZIP ? 0u : 1u, in, in_off, nullptr, n,
-                                total_in, max_item, sums);
+                                total_in, max_item, sums, trusted_max);
         if (r != RSX_OK) return r;
     }
     deflate_gather_kernel<<<(uint32_t)n, 256, 0, e->stream>>>(format, level, in_off, (uint32_t)n,

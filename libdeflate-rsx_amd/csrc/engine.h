@@ -18,10 +18,16 @@ struct rsx_engine {
     std::mutex mu;
     std::string err;
 
-    // grow-only device workspace, carved per call by ws_take()
+    // grow-only device workspace (ws), carved per call by ws_take() from the arena the call selected
     uint8_t *ws = nullptr;
     size_t ws_size = 0;
+    uint8_t *arena = nullptr;
+    size_t arena_size = 0;
     size_t ws_used = 0;
+
+    int num_cus = 0;           // multiprocessors of this engine's GPU
+    bool inflate_stats = false;  // RSX_INFLATE_STATS was set when the engine was created
+    bool inflate_split = true;   // two-kernel decoder (RSX_INFLATE_FUSED=1 at engine creation turns it off)
 
     // constant tables in device memory (built once in rsx_engine_create)
     uint32_t *d_crc_tables = nullptr;  // see checksum.hip for the layout
@@ -39,9 +45,9 @@ struct rsx_engine {
         }                                                                             \
     } while (0)
 
-// Ensures the workspace holds at least `bytes` and resets the carve pointer.
+// Ensures the workspace holds at least `bytes`, makes it the arena and resets the carve pointer.
 int ws_reserve(rsx_engine *e, size_t bytes);
-// Carves `bytes` (256-byte aligned) out of the reserved workspace; nullptr if exhausted.
+// Carves `bytes` (256-byte aligned) out of the arena; nullptr if exhausted.
 void *ws_take(rsx_engine *e, size_t bytes);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -59,20 +65,24 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 int checksum_tables_create(rsx_engine *e);
 size_t checksum_ws_bytes(size_t n, uint64_t total_in);
 // items are in[starts[i] .. starts[i] + len_i) with len_i = lens ? lens[i] : starts[i+1]-starts[i];
-// total_in bounds the sum of lengths, max_item the largest one
+// total_in bounds the sum of lengths, max_item the largest one.  trusted_max: max_item was derived from
+// the offsets by this library (host entry points); a caller's word is not used to lay out the partials
 int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
                     const uint64_t *starts, const uint64_t *lens, size_t n, uint64_t total_in,
-                    uint64_t max_item, uint32_t *values);
+                    uint64_t max_item, uint32_t *values, bool trusted_max);
 
 // inflate.hip
-size_t inflate_ws_bytes(size_t n, uint64_t total_out);
+// split: the two-kernel decoder (tokens in the workspace) with the one-kernel decoder for what it leaves;
+// otherwise the one-kernel decoder alone (small workspace)
+size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool split);
 // total_out / max_out: sum and maximum of the output slot sizes
 int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off, size_t n,
                    uint64_t total_in, uint64_t total_out, uint64_t max_out, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status);
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split);
 
 // deflate.hip
 size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int level);
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
                    size_t n, uint64_t total_in, uint64_t max_item, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, int flush);
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, int flush,
+                   bool trusted_max);

@@ -52,12 +52,16 @@ constexpr int kT = 256;                       // threads per stream
 constexpr int kRingBits = 14;
 constexpr uint32_t kRing = 1u << kRingBits;   // LDS mirror of the newest output bytes
 constexpr uint32_t kRingMask = kRing - 1;
-constexpr uint32_t kWinBytes = 4096;          // staged compressed bytes per round: one 16-byte load per lane
+constexpr uint32_t kWinBytes = 4096;          // staged compressed bytes per round of the one-kernel decoder: one 16-byte load per lane
 constexpr uint32_t kWinWords = kWinBytes / 4;
 // a token may start only while two dwords past its last fetch are still staged:
 // litlen fetch at b, offset fetch at most 20 bits later, each reads words w, w+1
-constexpr uint32_t kWinLimitBits = (kWinWords - 2) * 32 - 20;
-constexpr uint32_t kSubBits = 126;            // compressed bits per lane and round
+constexpr uint32_t win_limit_bits(uint32_t win_words) { return (win_words - 2) * 32 - 20; }
+constexpr uint32_t kWinLimitBits = win_limit_bits(kWinWords);
+#ifndef RSX_SUB_BITS
+#define RSX_SUB_BITS 126
+#endif
+constexpr uint32_t kSubBits = RSX_SUB_BITS;   // compressed bits per lane and round
 // one lane decodes at most kSubBits/2 matches of 258 bytes (a match token is
 // at least 2 bits), so a round that commits at least lane 0 always fits
 constexpr uint32_t kRoundOut = 16384 - 16;    // output bytes per round
@@ -68,7 +72,9 @@ constexpr uint32_t kMaxMatches = 1792;        // match queue entries per round
 constexpr uint32_t kWarmBits = RSX_WARM_BITS;  // warm-up in front of a sub-sequence's first guess
 constexpr uint32_t kCopySub = 2048;           // output bytes resolved per copy step (u16 pointers fit in win)
 static_assert(kCopySub * 2 <= kWinBytes, "copy pointers live in the window buffer");
+#ifndef RSX_EXPERIMENT
 static_assert(kSubBits / 2 * 258 <= kRoundOut && kSubBits / 2 <= kMaxMatches, "lane 0 must fit");
+#endif
 // up to 15 bytes of a round stay unflushed (16-byte store granularity): the next round
 // must not overwrite them in the ring
 static_assert(kRoundOut + 16 <= kRing, "a round may not lap the unflushed tail in the ring");
@@ -156,20 +162,30 @@ struct SpecScratch {
     uint16_t work[kT];            // compacted list of sub-sequences to re-decode
     uint32_t lane_exit[kT];       // where each sub-sequence ended (dead once the emit pass fills the queue)
 };
+struct TokSpecScratch {           // the speculation passes of the token decoder
+    uint32_t sub_start[kT];       // start handed to a sub-sequence that is re-decoded
+    uint32_t info[kT];            // tokens | matches << 8 | bytes << 16 of each sub-sequence
+    uint16_t work[kT];            // compacted list of sub-sequences to re-decode
+    uint32_t lane_exit[kT];       // where each sub-sequence ended
+};
 struct MatchQueue {
     // Only where each match starts.  Its distance and length wait in the ring, in the first three
     // of the bytes the match will produce (dist - 1 low, high, len - 3): nobody reads those bytes
     // as data before the copy phase has written them.
     uint16_t dst[kMaxMatches];    // dst - round_start
 };
-struct __align__(16) StreamLds {
+template <uint32_t kWinBytesT, uint32_t kRingT>
+struct __align__(16) StreamLdsT {
+    static constexpr uint32_t kWinBytes = kWinBytesT, kWinWords = kWinBytesT / 4;
+    static constexpr uint32_t kWinLimitBits = win_limit_bits(kWinWords);
     uint32_t win[kWinWords + 4];      // staged input (first: its LDS address is 0, so indexing it costs no add);
                                       // reused as u16 source pointers by the copy phase
-    uint8_t ring[kRing];
+    uint8_t ring[kRingT];
     uint32_t tab[kTabLitlen + kLitlenEnough];   // decode tables: offset at index 0, litlen at kTabLitlen
     union {
         HeaderScratch hdr;
         SpecScratch spec;
+        TokSpecScratch tspec;
         MatchQueue mq;
     };
     uint32_t scan_carry[2 * (kT / 64) + 4];   // scans and flags; the last four: the copy phase's spanning match
@@ -191,6 +207,7 @@ struct __align__(16) StreamLds {
 
 // The serial header code sits behind non-inlined calls.  Its LDS operands carry their
 // address space in the type: through plain pointers every access would be a flat one.
+typedef StreamLdsT<kWinBytes, kRing> StreamLds;   // the one-kernel decoder's
 #define RSX_LDS __attribute__((address_space(3)))
 typedef RSX_LDS StreamLds LdsStream;
 
@@ -428,8 +445,10 @@ struct StreamCtx {
 
 // Stage kWinBytes of compressed input around the current bit position.  Returns
 // (through *win_bit0) the body-relative bit position of window bit 0.
-__device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *win_bit0)
+template <class LS>
+__device__ inline void stage_window(LS &L, const StreamCtx &c, int64_t *win_bit0)
 {
+    constexpr uint32_t kWinBytes = LS::kWinBytes, kWinWords = LS::kWinWords;
     const uint64_t byte_pos = L.bitpos >> 3;
     const uint8_t *cur = c.body + byte_pos;
     const uint8_t *wbase = cur - ((uintptr_t)cur & 15);
@@ -439,24 +458,32 @@ __device__ inline void stage_window(StreamLds &L, const StreamCtx &c, int64_t *w
     // unit never crosses a page); bytes at or after the end of the body read as 0
     const uint8_t *alloc_lo = c.in_alloc - ((uintptr_t)c.in_alloc & 15);
     const uint8_t *alloc_hi = c.in_alloc + c.in_alloc_len;
-    for (uint32_t u = threadIdx.x; u < kWinBytes / 16; u += kT) {
-        const uint8_t *unit = wbase + 16 * (size_t)u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (unit >= alloc_lo && unit < alloc_hi && unit < body_end) {
-            v = *reinterpret_cast<const uint4 *>(unit);
-            if (unit + 16 > body_end) {
-                uint32_t keep = (uint32_t)(body_end - unit);  // 1..15 valid bytes
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    constexpr uint32_t kUnits = kWinBytes / 16, kPerLane = (kUnits + kT - 1) / kT;
+    uint4 v[kPerLane];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int valid = (int)keep - 4 * k;  // bytes of this word that are valid
-                    if (valid <= 0) w[k] = 0;
-                    else if (valid < 4) w[k] &= (1u << (8 * valid)) - 1;
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+    for (uint32_t i = 0; i < kPerLane; i++) {   // (every load is issued before the first one is needed)
+        const uint32_t u = threadIdx.x + i * kT;
+        const uint8_t *unit = wbase + 16 * (size_t)u;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (u < kUnits && unit >= alloc_lo && unit < alloc_hi && unit < body_end)
+            v[i] = *reinterpret_cast<const uint4 *>(unit);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kPerLane; i++) {
+        const uint32_t u = threadIdx.x + i * kT;
+        const uint8_t *unit = wbase + 16 * (size_t)u;
+        if (unit < body_end && unit + 16 > body_end) {
+            uint32_t keep = (uint32_t)(body_end - unit);  // 1..15 valid bytes
+            uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int valid = (int)keep - 4 * k;  // bytes of this word that are valid
+                if (valid <= 0) w[k] = 0;
+                else if (valid < 4) w[k] &= (1u << (8 * valid)) - 1;
             }
+            v[i] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        reinterpret_cast<uint4 *>(L.win)[u] = v;
+        if (u < kUnits) reinterpret_cast<uint4 *>(L.win)[u] = v[i];
     }
     if (threadIdx.x < 4) L.win[kWinWords + threadIdx.x] = 0;
 }
@@ -470,7 +497,8 @@ struct HeaderResult {
     int code;      // DecompressResult
     uint32_t b;    // window bit position behind the header (by value: no pointer into the caller's stack)
 };
-__device__ __noinline__ HeaderResult read_dynamic_header(LdsStream &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
+template <class LS>
+__device__ __noinline__ HeaderResult read_dynamic_header(LS &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
 {
     auto avail = [&](uint32_t need) { return (uint64_t)(win_bit0 + b + need) <= end_bit; };
     if (!avail(14)) return HeaderResult{RSX_SHORT_INPUT, b};
@@ -530,7 +558,8 @@ __device__ __noinline__ HeaderResult read_dynamic_header(LdsStream &L, uint32_t 
 }
 
 // src/decompress/mod.rs:355-401: the code lengths of the static code (by the wave)
-__device__ inline void load_static_lens(LdsStream &L)
+template <class LS>
+__device__ inline void load_static_lens(LS &L)
 {
     for (uint32_t i = threadIdx.x & 63; i < 320; i += 64)
         L.hdr.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
@@ -541,8 +570,10 @@ __device__ inline void load_static_lens(LdsStream &L)
 // First wave's part of a round: when the stream is between blocks, lane 0 reads the next
 // block header from the staged window (src/decompress/mod.rs:225-252), then the wave builds
 // the decode tables.  Leaves L.in_block / L.stored_len / L.status / L.restage set.
-__device__ __noinline__ void parse_block_header(LdsStream &L, const StreamCtx &c, int64_t win_bit0)
+template <class LS>
+__device__ __noinline__ void parse_block_header(LS &L, const StreamCtx &c, int64_t win_bit0)
 {
+    constexpr uint32_t kWinLimitBits = LS::kWinLimitBits;
     const uint64_t end_bit = c.body_len * 8;
     uint32_t b = (uint32_t)((int64_t)L.bitpos - win_bit0);
     L.restage = 0;
@@ -595,7 +626,8 @@ __device__ __noinline__ void parse_block_header(LdsStream &L, const StreamCtx &c
     L.hdr.after = b;
 }
 
-__device__ __noinline__ void header_step(LdsStream &L, const StreamCtx &c, int64_t win_bit0)
+template <class LS>
+__device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_bit0)
 {
     if (threadIdx.x == 0) parse_block_header(L, c, win_bit0);
     WAVE_SYNC();
@@ -643,7 +675,8 @@ struct Decoder {
     uint32_t tbase;  // byte offset of the table of the next lookup
     uint32_t tbits;  // index width of the next lookup
 
-    __device__ inline void init(const StreamLds &L, uint32_t at, uint32_t litlen_bits)
+    template <class LS>
+    __device__ inline void init(const LS &L, uint32_t at, uint32_t litlen_bits)
     {
         const uint32_t w = at >> 5;
         w0 = L.win[w];
@@ -666,8 +699,8 @@ struct StepOut {
 
 // kValues = false: only the token boundaries matter (literal bytes, lengths and distances are
 // not computed)
-template <bool kValues = true>
-__device__ inline StepOut decoder_step(const StreamLds &L, Decoder &d)
+template <bool kValues = true, class LS>
+__device__ inline StepOut decoder_step(const LS &L, Decoder &d)
 {
     const uint32_t bits = __builtin_amdgcn_alignbit(d.w1, d.w0, d.b);   // 32 bits from bit b on
     const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.tab) + d.tbase +
@@ -709,8 +742,8 @@ struct Scan {
 // (window relative).  Bits past the body read as zero; a step that runs past the
 // body stops the chain at the start of its token (ShortInput when it is real).
 // kEndFar: the body ends behind everything a step can reach from this window, so no step runs past it
-template <bool kEndFar>
-__device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bound, int64_t end_b,
+template <bool kEndFar, class LS>
+__device__ inline Scan scan_span(const LS &L, uint32_t start, uint32_t bound, int64_t end_b,
                                  uint32_t litlen_bits)
 {
     Decoder d;
@@ -749,7 +782,8 @@ __device__ inline Scan scan_span(const StreamLds &L, uint32_t start, uint32_t bo
 // stretch of warm-up the decoder is often on real token boundaries already.  An end-of-block
 // code does not stop the warm-up: when it is real, the lanes behind it are not part of this
 // round anyway, and when it is not, decoding on may still find the boundaries.
-__device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_t lo, int64_t end_b,
+template <class LS>
+__device__ inline uint32_t warm_start(const LS &L, uint32_t from, uint32_t lo, int64_t end_b,
                                       uint32_t litlen_bits)
 {
     Decoder d;
@@ -767,7 +801,8 @@ __device__ inline uint32_t warm_start(const StreamLds &L, uint32_t from, uint32_
 }
 
 // exclusive prefix sums of two 32-bit values over the workgroup
-__device__ inline void wg_exclusive_scan2(StreamLds &L, uint32_t a, uint32_t b, uint32_t *ea,
+template <class LS>
+__device__ inline void wg_exclusive_scan2(LS &L, uint32_t a, uint32_t b, uint32_t *ea,
                                           uint32_t *eb)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -811,6 +846,9 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     const uint32_t lo = b0 + tid * kSubBits;
     uint32_t bound = lo + kSubBits;
     if (bound > kWinLimitBits) bound = kWinLimitBits;
+    // lanes whose sub-sequence lies behind the window take no part in the round (uniform count)
+    const uint32_t n_active = (kWinLimitBits - b0 + kSubBits - 1) / kSubBits < (uint32_t)kT
+                                  ? (kWinLimitBits - b0 + kSubBits - 1) / kSubBits : (uint32_t)kT;
 
     // ---- passes 1..k: find every sub-sequence's true start ------------------------
     // A lane that decodes an end-of-block (or runs out of input) while its start is
@@ -846,7 +884,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
             uint32_t pe = L.spec.lane_exit[tid - 1];
             if (!(pe & (kExitEob | kExitStop))) ns = pe;
         }
-        const bool need = ns != start;
+        const bool need = ns != start && (uint32_t)tid < n_active;
         start = ns;
         // compact the sub-sequences that need another decode
         const unsigned long long bal = __ballot(need);
@@ -896,7 +934,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
     WG_SYNC();
     if (sc.exit & (kExitEob | kExitStop)) atomicMin(&L.first_flag, (uint32_t)tid);
     WG_SYNC();
-    const bool live = (uint32_t)tid <= L.first_flag;
+    const bool live = (uint32_t)tid <= L.first_flag && (uint32_t)tid < n_active;
     if (!live) {
         sc.bytes = 0;
         sc.nm = 0;
@@ -984,7 +1022,8 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
 // front of it -- in log2(chain length) rounds, whatever the dependency depth
 // between matches, overlapping (run-length) matches included.  One gather finishes
 // the step.  The pointers live in the window buffer, which is idle during the copy.
-__device__ void copy_round(StreamLds &L, const StreamCtx &c)
+template <class LS>
+__device__ void copy_round(LS &L, const StreamCtx &c)
 {
     const uint32_t nm = L.num_matches;
     const uint32_t round_start = L.round_start_lo;
@@ -1143,7 +1182,8 @@ __device__ void copy_round(StreamLds &L, const StreamCtx &c)
 // All lanes: write output positions [from, to) from the ring to global memory.
 // from is on a 16-byte boundary of the global address (or 0); full units use
 // 16-byte stores, the ragged first / last unit byte stores.
-__device__ void flush_range(StreamLds &L, const StreamCtx &c, uint32_t from, uint32_t to)
+template <class LS>
+__device__ void flush_range(LS &L, const StreamCtx &c, uint32_t from, uint32_t to)
 {
     if (to <= from) return;   // (uniform)
     const uint32_t g_from = from + c.shift, g_to = to + c.shift;  // = global address mod-16 phase
@@ -1225,7 +1265,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
-    unsigned long long *__restrict__ stats)
+    unsigned long long *__restrict__ stats, int only_status)
 {
     unsigned long long tS = 0, tH = 0, tD = 0, tC = 0, tF = 0, t0 = 0, nRounds = 0;
 #define STAT_BEGIN() do { if (STATS) t0 = clock64(); } while (0)
@@ -1233,12 +1273,14 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     __shared__ StreamLds L;
     const uint32_t item = blockIdx.x;
     if (item >= n) return;
+    // only_status != 0: this launch only takes the streams another kernel has marked with it (uniform)
+    if (only_status && status[item] != only_status) return;
     const int tid = threadIdx.x;
 
     const uint64_t ib = in_off[item], ie = in_off[item + 1];
     const uint64_t ob = out_off[item], oe = out_off[item + 1];
     StreamCtx c;
-    c.in_alloc = in;
+    c.in_alloc = in + in_off[0];   // the batch's bytes are in[in_off[0] .. in_off[0] + total_in)
     c.in_alloc_len = total_in;
     c.out = out + ob;
     c.out_cap = oe - ob;
@@ -1406,6 +1448,566 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
 #undef STAT_END
 }
 
+// =====================================================================================
+// The two-kernel decoder: inflate_decode_kernel turns the Huffman-coded body of every
+// stream into an array of LZ77 tokens in device memory, inflate_expand_kernel turns the
+// tokens into bytes.  Splitting the work frees each half from the other's LDS: the first
+// kernel has no output ring, so one round can hold 256 sub-sequences of up to 504 bits (a
+// 16 KiB window) and the warm-up in front of a sub-sequence is no longer several times its
+// length; the second has no decode tables and no serial decoding at all.  Both leave every
+// anomaly (a damaged stream, an output slot that is too small, a stream that needs more
+// token space than the workspace has) to inflate_kernel above, which then decodes that
+// stream again from its start and reports the reference's status code: the two kernels
+// only ever finish streams that decode cleanly.
+//
+// Token array of a stream: rows of 256 words.  A round of the first kernel owns a header
+// row (word l: decoder steps | matches << 8 | output bytes << 16 of sub-sequence l), kSegRows rows of
+// running totals (row p: output bytes | matches << 16 of the first 16 p steps of every sub-sequence,
+// so that the second kernel can start in the middle of one), and then
+// as many rows as its longest sub-sequence took decoder steps; row k holds what the k-th step of
+// every sub-sequence finished: a literal's byte, a match (1 << 31 | distance - 1 << 8 |
+// length - 3) or kNoTok (a length still waiting for its distance, a subtable hop, the end of
+// the block).  A row per step, not per token, keeps the lanes of a wave on the same row: every
+// store is one contiguous 256 bytes.  Rounds are listed in a per-stream array of RoundRec.
+
+// -DRSX_SPLIT_TIMERS=1: phase timers of the two kernels (development aid), summed over all streams:
+// 0 stage 1 header 2 warm-up 3 first scan 4 later passes 5 round tail 6 rounds 7 passes
+// 8 expand: records+scan 9 walk 10 copy 11 flush 12 groups 13 stored
+#ifndef RSX_SPLIT_TIMERS
+#define RSX_SPLIT_TIMERS 0
+#endif
+#if RSX_SPLIT_TIMERS
+static __device__ unsigned long long g_split_t[16];
+#define SPLIT_T_ADD(k, v) atomicAdd(&g_split_t[k], (unsigned long long)(v))
+#define SPLIT_T_NOW() clock64()
+#else
+#define SPLIT_T_ADD(k, v) do { } while (0)
+#define SPLIT_T_NOW() 0ull
+#endif
+
+constexpr int32_t kStatusPending = -2;    // decoded into tokens, not expanded yet
+constexpr int32_t kStatusFallback = -3;   // left to inflate_kernel
+constexpr uint32_t kTokCap = 96;          // decoder steps (token slots) per sub-sequence and round
+constexpr uint32_t kNoTok = 0x100;        // a slot whose step finished no token
+constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence in pieces of this many steps
+constexpr uint32_t kSegRows = kTokCap / kSegSteps - 1;   // header rows 1..kSegRows: bytes | matches << 16 in front of piece p
+constexpr uint32_t kHdrRows = 1 + kSegRows;
+static_assert(kTokCap % kSegSteps == 0, "whole pieces");
+constexpr uint32_t kLaneBytesStop = 8192; // a sub-sequence stops once it has produced this many bytes
+static_assert(kLaneBytesStop + 258 <= kRoundOut, "one sub-sequence must fit a round of the expander");
+static_assert(kTokCap <= kMaxMatches, "one sub-sequence must fit the match queue");
+#ifndef RSX_DEC_SUB_BITS
+#define RSX_DEC_SUB_BITS 504
+#endif
+#ifndef RSX_DEC_WARM_BITS
+#define RSX_DEC_WARM_BITS 504
+#endif
+constexpr uint32_t kDecSubMax = RSX_DEC_SUB_BITS;      // longest sub-sequence (bits)
+constexpr uint32_t kDecSubMin = 32;
+constexpr uint32_t kDecWarm = RSX_DEC_WARM_BITS;
+constexpr uint32_t kDecWinBytes = (kT * kDecSubMax / 8 + 256 + 15) / 16 * 16;   // the window of one round
+constexpr uint32_t kExitFull = 1u << 29;  // the sub-sequence stopped early: token or byte limit
+
+enum { ROUND_END = 0, ROUND_TOKENS = 1, ROUND_STORED = 2 };
+struct RoundRec {
+    uint32_t kind;      // ROUND_*
+    uint32_t a;         // tokens: first row (the header row);   stored: length in bytes
+    uint32_t b;         // tokens: number of sub-sequences;       stored: low half of the source offset in the body
+    uint32_t c;         //                                        stored: high half
+};
+
+// where a stream's token rows and round records live (both kernels compute the same)
+struct SplitLayout {
+    uint32_t *tok;          // token rows of all streams
+    RoundRec *rounds;       // round records of all streams
+    // rel = the stream's input offset minus the batch's first
+    __device__ uint64_t first_row(uint64_t rel, uint32_t item) const
+    {
+        return (rel * 8 >> 10) + (uint64_t)item * (kTokCap + kHdrRows + 1);
+    }
+    __device__ uint64_t row_budget(uint64_t in_len) const { return (in_len * 8 >> 10) + kTokCap + kHdrRows; }
+    __device__ uint64_t first_round(uint64_t rel, uint32_t item) const { return (rel >> 8) + (uint64_t)item * 66; }
+    __device__ uint64_t round_budget(uint64_t in_len) const { return (in_len >> 8) + 64; }
+};
+static inline uint64_t split_tok_rows(size_t n, uint64_t total_in) { return (total_in * 8 >> 10) + n * (kTokCap + kHdrRows + 1) + 2; }
+static inline uint64_t split_round_recs(size_t n, uint64_t total_in) { return (total_in >> 8) + n * 66 + 2; }
+
+typedef StreamLdsT<kDecWinBytes, 16> DecodeLds;
+typedef RSX_LDS DecodeLds LdsDecode;
+
+struct TokScan {
+    uint32_t exit;   // where the next sub-sequence starts (window bit) | kExit* flags
+    uint32_t info;   // steps | matches << 8 | bytes << 16
+};
+
+// scan_span that also writes the tokens it decodes: hdr = this sub-sequence's word of the round's first
+// header row; what step k finished goes to hdr[(kHdrRows + k) * kT], the totals in front of piece p to hdr[p * kT]
+template <bool kEndFar, class LS>
+__device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t bound, int64_t end_b,
+                                      uint32_t litlen_bits, uint32_t *__restrict__ hdr)
+{
+    uint32_t *__restrict__ col = hdr + kHdrRows * kT;
+    Decoder d;
+    d.init(L, start, litlen_bits);
+    const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
+    uint32_t tok = start;   // where the token in flight starts
+    uint32_t bytes = 0, nm = 0, kind = kTokNone;
+    uint32_t steps = 0;   // (the same in every lane that is still running)
+    bool over = false, full = false;
+    bool running = start < bound;
+    while (running) {
+        const StepOut o = decoder_step(L, d);
+        kind = o.kind;
+        over = !kEndFar && d.b > end32;
+        const bool is_match = kind == kTokMatch;
+        const bool fin = kind >= kTokLit && !over;   // a literal or a match ends with this step, inside the body
+        const uint32_t rec = is_match ? (0x80000000u | ((o.value - 1) << 8) | (o.len - 3)) : o.value;
+        col[steps * kT] = fin ? rec : kNoTok;
+        steps++;
+        bytes += fin ? (is_match ? o.len : 1u) : 0u;
+        nm += (fin && is_match) ? 1u : 0u;
+        if ((steps & (kSegSteps - 1)) == 0) hdr[(steps / kSegSteps) * kT] = bytes | (nm << 16);   // (uniform)
+        tok = fin ? d.b : tok;
+        // (a sub-sequence stops early only at the end of a token)
+        full = fin && (steps + 4 >= kTokCap || bytes >= kLaneBytesStop);
+        running = !over && kind != kTokEob && !full && (kind < kTokLit || d.b < bound);
+    }
+    TokScan r;
+    r.info = steps | (nm << 8) | (bytes << 16);
+    r.exit = over ? (tok | kExitStop) : kind == kTokEob ? (d.b | kExitEob) : (full && d.b < bound) ? (d.b | kExitFull) : d.b;
+    return r;
+}
+
+// One round of the first kernel: all lanes decode the Huffman block body in the staged window from
+// L.bitpos on, sub-sequences of `sub_bits` bits, and leave the tokens in this round's rows.  Returns
+// (uniform) the number of rows the round used, header row included, or 0 when it must not be recorded
+// (an error: L.status is set).  *sub_next receives the sub-sequence length to use for the next round.
+__device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_t win_bit0, uint32_t sub_bits,
+                                        uint32_t *__restrict__ rows, uint32_t *nlanes_ret, uint32_t *sub_next)
+{
+    constexpr uint32_t kWinLimitBits = DecodeLds::kWinLimitBits;
+    const int tid = threadIdx.x;
+    const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
+    const int64_t end_b = (int64_t)(c.body_len * 8) - win_bit0;  // first bit past the body
+    const uint32_t litlen_bits = L.litlen_tablebits;
+    const bool end_far = end_b > (int64_t)kWinLimitBits + 64;
+    const uint32_t lo = b0 + tid * sub_bits;
+    uint32_t bound = lo + sub_bits;
+    if (bound > kWinLimitBits) bound = kWinLimitBits;
+    uint32_t n_active = (kWinLimitBits - b0 + sub_bits - 1) / sub_bits;
+    if (n_active > (uint32_t)kT) n_active = kT;
+    uint32_t *col = rows + tid;        // this lane's word of the first header row
+
+    uint32_t guess = lo;
+    unsigned long long tq = SPLIT_T_NOW();
+    if (tid > 0 && lo < bound) guess = warm_start(L, lo - b0 > kDecWarm ? lo - kDecWarm : b0, lo, end_b, litlen_bits);
+    if (RSX_SPLIT_TIMERS && tid == 64) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(2, t - tq); tq = t; }
+    uint32_t start = guess;
+    TokScan sc;
+    if (start >= bound) {
+        sc = TokScan{start, 0};
+    } else {
+        sc = end_far ? scan_tokens<true>(L, start, bound, end_b, litlen_bits, col)
+                     : scan_tokens<false>(L, start, bound, end_b, litlen_bits, col);
+    }
+    L.tspec.lane_exit[tid] = sc.exit;
+    L.tspec.info[tid] = sc.info;
+    WG_SYNC();
+    if (RSX_SPLIT_TIMERS && tid == 64) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(3, t - tq); tq = t; }
+    // passes until every sub-sequence starts where its predecessor ended (as decode_round_parallel)
+    for (int pass = 0; pass <= kT; pass++) {
+        WG_SYNC();
+        uint32_t ns = guess;
+        if (tid > 0) {
+            const uint32_t pe = L.tspec.lane_exit[tid - 1];
+            if (!(pe & (kExitEob | kExitStop | kExitFull))) ns = pe;
+        }
+        const bool need = ns != start && (uint32_t)tid < n_active;
+        start = ns;
+        const unsigned long long bal = __ballot(need);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) L.scan_carry[w] = (uint32_t)__popcll(bal);
+        if (need) L.tspec.sub_start[tid] = start;
+        WG_SYNC();
+        uint32_t before = 0, total = 0;
+        for (int k = 0; k < kT / 64; k++) {
+            const uint32_t cnt = L.scan_carry[k];
+            if (k < w) before += cnt;
+            total += cnt;
+        }
+        if (total == 0) break;
+        if (RSX_SPLIT_TIMERS && tid == 64) SPLIT_T_ADD(7, 1);
+        if (need) L.tspec.work[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)tid;
+        WG_SYNC();
+        if ((uint32_t)tid < total) {
+            const uint32_t i = L.tspec.work[tid];
+            const uint32_t st_i = L.tspec.sub_start[i];
+            uint32_t bound_i = b0 + (i + 1) * sub_bits;
+            if (bound_i > kWinLimitBits) bound_i = kWinLimitBits;
+            TokScan r;
+            if (st_i >= bound_i) {
+                r = TokScan{st_i, 0};
+            } else {
+                r = end_far ? scan_tokens<true>(L, st_i, bound_i, end_b, litlen_bits, rows + i)
+                            : scan_tokens<false>(L, st_i, bound_i, end_b, litlen_bits, rows + i);
+            }
+            L.tspec.lane_exit[i] = r.exit;
+            L.tspec.info[i] = r.info;
+        }
+    }
+    WG_SYNC();
+    if (RSX_SPLIT_TIMERS && tid == 64) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(4, t - tq); tq = t; }
+    sc.exit = L.tspec.lane_exit[tid];
+    sc.info = L.tspec.info[tid];
+    if (tid == 0) L.first_flag = n_active - 1;
+    WG_SYNC();
+    if ((sc.exit & (kExitEob | kExitStop | kExitFull)) && (uint32_t)tid < n_active) atomicMin(&L.first_flag, (uint32_t)tid);
+    WG_SYNC();
+    const uint32_t last = L.first_flag;   // the round ends with this sub-sequence
+    const bool live = (uint32_t)tid <= last;
+    // header row, the longest column, totals for the next round's sub-sequence length
+    if (live) rows[tid] = sc.info;
+    uint32_t mx = live ? (sc.info & 0xFF) : 0u, tk = mx, by = live ? (sc.info >> 16) : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+        tk += __shfl_xor(tk, o);
+        by += __shfl_xor(by, o);
+    }
+    if ((tid & 63) == 0) {
+        L.scan_carry[tid >> 6] = mx;
+        L.scan_carry[4 + (tid >> 6)] = tk;
+        L.scan_carry[8 + (tid >> 6)] = by;
+    }
+    WG_SYNC();
+    mx = max(max(L.scan_carry[0], L.scan_carry[1]), max(L.scan_carry[2], L.scan_carry[3]));
+    tk = L.scan_carry[4] + L.scan_carry[5] + L.scan_carry[6] + L.scan_carry[7];
+    by = L.scan_carry[8] + L.scan_carry[9] + L.scan_carry[10] + L.scan_carry[11];
+    const uint32_t last_exit = L.tspec.lane_exit[last];
+    WG_SYNC();
+    const uint32_t consumed = (last_exit & kExitPosMask) - b0;
+    // next round: aim at 5/8 of the token limit and 3/4 of the byte limit per sub-sequence
+    {
+        uint32_t s = kDecSubMax;
+        if (tk) s = min(s, (uint32_t)((uint64_t)consumed * (kTokCap * 5 / 8) / tk));   // (tk: decoder steps)
+        if (by) s = min(s, (uint32_t)((uint64_t)consumed * (kLaneBytesStop * 3 / 4) / by));
+        if (last_exit & kExitFull) s = min(s, sub_bits / 2);
+        *sub_next = max(s, kDecSubMin);
+    }
+    *nlanes_ret = last + 1;
+    if (tid == 0) {
+        L.bitpos = (uint64_t)(win_bit0 + (int64_t)(last_exit & kExitPosMask));
+        if (last_exit & kExitStop) {
+            L.status = RSX_SHORT_INPUT;   // (any failure sends the stream to inflate_kernel)
+        } else if (last_exit & kExitEob) {
+            L.in_block = 0;
+            if (L.final_block) L.status = RSX_SUCCESS;
+        }
+    }
+    WG_SYNC();
+    if (RSX_SPLIT_TIMERS && tid == 64) { SPLIT_T_ADD(5, SPLIT_T_NOW() - tq); SPLIT_T_ADD(6, 1); }
+    return kHdrRows + mx;
+}
+
+__global__ __launch_bounds__(kT, 5) void inflate_decode_kernel(
+    int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
+    uint64_t total_in, int32_t *__restrict__ status, uint64_t *__restrict__ body_end, SplitLayout lay)
+{
+    __shared__ DecodeLds L;
+    const uint32_t item = blockIdx.x;
+    if (item >= n) return;
+    const int tid = threadIdx.x;
+    const uint64_t ib = in_off[item], ie = in_off[item + 1];
+    StreamCtx c;
+    const uint64_t in_base = in_off[0];
+    c.in_alloc = in + in_base;
+    c.in_alloc_len = total_in;
+    c.out = nullptr;
+    c.out_cap = 0;
+    c.shift = 0;
+    const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
+    if (ci.status >= 0) {   // (uniform) inflate_kernel reports it
+        if (tid == 0) status[item] = kStatusFallback;
+        return;
+    }
+    c.body = in + ib + ci.hdr;
+    c.body_len = (ie - ib) - ci.hdr - ci.trailer;
+    uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, item) * kT;
+    RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
+    const uint64_t row_budget = lay.row_budget(ie - ib), round_budget = lay.round_budget(ie - ib);
+    uint64_t row = 0, nrounds = 0;   // (uniform)
+
+    if (tid == 0) {
+        L.bitpos = 0;
+        L.status = -1;
+        L.in_block = 0;
+        L.final_block = 0;
+        L.stored_len = -1;
+        L.restage = 0;
+    }
+    uint32_t sub_bits = kDecSubMax;
+    uint64_t seen_bitpos = ~0ull;
+    int stalled = 0;
+    bool bail = false;
+    WG_SYNC();
+    for (;;) {
+        {
+            const uint64_t bp = L.bitpos;
+            stalled = bp == seen_bitpos ? stalled + 1 : 0;
+            seen_bitpos = bp;
+            WG_SYNC();
+            if (stalled > 4) {
+                bail = true;
+                break;
+            }
+        }
+        // room for one more round and its record, and for the end record behind it
+        if (row + kTokCap + kHdrRows > row_budget || nrounds + 2 > round_budget) {
+            bail = true;
+            break;
+        }
+        int64_t win_bit0;
+        unsigned long long ts = SPLIT_T_NOW();
+        stage_window(L, c, &win_bit0);
+        WG_SYNC();
+        if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(0, t - ts); ts = t; }
+        if (!L.in_block) {
+            WG_SYNC();
+            if (tid < 64) header_step(*(LdsDecode *)&L, c, win_bit0);
+            WG_SYNC();
+            if (RSX_SPLIT_TIMERS && tid == 0) SPLIT_T_ADD(1, SPLIT_T_NOW() - ts);
+        }
+        const int restage = L.restage, st0 = L.status, stored0 = L.stored_len;
+        const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
+        WG_SYNC();
+        if (restage) {
+            if (tid == 0) L.restage = 0;
+            continue;
+        }
+        if (st0 < 0 && stored0 < 0) {
+            if (b0 + sub_bits + 64 > DecodeLds::kWinLimitBits) continue;
+            uint32_t nlanes = 0, sub_next = sub_bits;
+            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, tok + row * kT, &nlanes, &sub_next);
+            sub_bits = sub_next;
+            if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, 0};
+            row += used;
+            nrounds++;
+        }
+        const int st = L.status;
+        const int32_t stored = L.stored_len;
+        WG_SYNC();
+        if (st < 0 && stored >= 0) {
+            // stored block body (src/decompress/mod.rs:305-346): the expander copies it
+            const uint64_t src_byte = L.bitpos >> 3;
+            if ((uint64_t)stored > c.body_len - src_byte) {
+                bail = true;   // ShortInput
+                break;
+            }
+            if (tid == 0) {
+                rounds[nrounds] = RoundRec{ROUND_STORED, (uint32_t)stored, (uint32_t)src_byte, (uint32_t)(src_byte >> 32)};
+                L.stored_len = -1;
+                L.bitpos += (uint64_t)stored * 8;
+                if (L.final_block) L.status = RSX_SUCCESS;
+            }
+            nrounds++;
+            WG_SYNC();
+            if (L.status >= 0) break;
+            continue;
+        }
+        if (st >= 0) break;
+    }
+    if (tid == 0) {
+        const bool ok = !bail && L.status == RSX_SUCCESS;
+        if (ok) rounds[nrounds] = RoundRec{ROUND_END, 0, 0, 0};
+        status[item] = ok ? kStatusPending : kStatusFallback;
+        body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
+    }
+}
+
+// LDS of the second kernel: the output ring, the copy phase's pointer table (named win: copy_round is
+// shared with inflate_kernel) and the match queue.
+struct __align__(16) ExpandLds {
+    uint32_t win[kWinWords + 4];
+    uint8_t ring[kRing];
+    MatchQueue mq;
+    uint32_t scan_carry[2 * (kT / 64) + 4];
+    uint32_t stat_copy;
+    unsigned long long stat_t[4];
+    uint32_t num_matches;
+    uint32_t round_start_lo, round_end_lo;
+    uint32_t group_end, base_bytes, base_nm;
+    uint32_t bail;
+    uint32_t lane_at[kT];    // per sub-sequence of the round: output bytes in front of it (from the round's start)
+    uint16_t lane_mi[kT];    // matches in front of it
+    uint8_t lane_steps[kT];  // its decoder steps
+};
+
+__global__ __launch_bounds__(kT, 5) void inflate_expand_kernel(
+    int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
+    uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
+    int32_t *__restrict__ status, SplitLayout lay)
+{
+    __shared__ ExpandLds L;
+    const uint32_t item = blockIdx.x;
+    if (item >= n) return;
+    if (status[item] != kStatusPending) return;   // (uniform)
+    const int tid = threadIdx.x;
+    const uint64_t ib = in_off[item], ie = in_off[item + 1];
+    const uint64_t ob = out_off[item], oe = out_off[item + 1];
+    StreamCtx c;
+    c.in_alloc = in;
+    c.in_alloc_len = 0;
+    c.out = out + ob;
+    c.out_cap = oe - ob;
+    c.shift = (uint32_t)((uintptr_t)c.out & 15);
+    // (the first kernel accepted the container: its header is parsed again for the body's place)
+    const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
+    c.body = in + ib + ci.hdr;
+    c.body_len = (ie - ib) - ci.hdr - ci.trailer;
+    const uint64_t in_base = in_off[0];
+    const uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, item) * kT;
+    const RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
+    const uint32_t cap = (uint32_t)c.out_cap;
+
+    if (tid == 0) {
+        L.bail = 0;
+        L.stat_copy = 0;
+        L.round_start_lo = 0;
+        L.round_end_lo = 0;
+        L.num_matches = 0;
+    }
+    uint32_t flushed = 0;   // output positions below this are in global memory (uniform)
+    uint32_t pos = 0;       // output position reached (uniform)
+    bool bail = false;
+    WG_SYNC();
+    auto flush_upto = [&](uint32_t upto_pos) {
+        uint32_t upto = ((upto_pos + c.shift) & ~15u);
+        upto = upto > c.shift ? upto - c.shift : 0;
+        if (upto < flushed) upto = flushed;
+        flush_range(L, c, flushed, upto);
+        flushed = upto;
+    };
+    for (uint64_t r = 0; !bail; r++) {
+        unsigned long long tb = SPLIT_T_NOW();
+        const RoundRec rec = rounds[r];
+        if (rec.kind == ROUND_END) break;
+        if (rec.kind == ROUND_STORED) {
+            const uint32_t len = rec.a;
+            const uint64_t src_byte = rec.b | ((uint64_t)rec.c << 32);
+            if (len > cap - pos) {
+                bail = true;   // InsufficientSpace
+                break;
+            }
+            flush_upto(pos);
+            const uint8_t *sp = c.body + src_byte;
+            for (uint32_t done = 0; done < len;) {
+                const uint32_t piece = len - done < kRoundOut ? len - done : kRoundOut;
+                for (uint32_t k = tid; k < piece; k += kT) L.ring[(pos + k + c.shift) & kRingMask] = sp[done + k];
+                WG_SYNC();
+                pos += piece;
+                done += piece;
+                flush_upto(pos);
+                WG_SYNC();
+            }
+            continue;
+        }
+        // a round of tokens: its sub-sequences go through the ring in groups that fit it
+        const uint32_t nlanes = rec.b;
+        const uint32_t *const rows = tok + (uint64_t)rec.a * kT;
+        const uint32_t info = (uint32_t)tid < nlanes ? rows[tid] : 0u;
+        const uint32_t ntok = info & 0xFF, nm = (info >> 8) & 0xFF, bytes = info >> 16;
+        uint32_t exb, exn;
+        wg_exclusive_scan2(L, bytes, nm, &exb, &exn);
+        L.lane_at[tid] = exb;
+        L.lane_mi[tid] = (uint16_t)exn;
+        L.lane_steps[tid] = (uint8_t)ntok;
+        if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(8, t - tb); tb = t; }
+        uint32_t g0 = 0;
+        while (g0 < nlanes) {
+            if (RSX_SPLIT_TIMERS && tid == 0) { tb = SPLIT_T_NOW(); SPLIT_T_ADD(12, 1); }
+            if ((uint32_t)tid == g0) {
+                L.base_bytes = exb;
+                L.base_nm = exn;
+                L.group_end = nlanes;
+            }
+            WG_SYNC();
+            const uint32_t bb = L.base_bytes, bn = L.base_nm;
+            const bool fits = exb + bytes - bb <= kRoundOut && exn + nm - bn <= kMaxMatches;
+            if ((uint32_t)tid > g0 && (uint32_t)tid < nlanes && !fits) atomicMin(&L.group_end, (uint32_t)tid);
+            WG_SYNC();
+            const uint32_t g1 = L.group_end;
+            const uint32_t round_start = pos;
+            if ((uint32_t)tid >= g0 && (uint32_t)tid < g1) {
+                // InsufficientSpace somewhere in this sub-sequence?
+                const uint32_t op0 = round_start + (exb - bb);
+                if (op0 > cap || bytes > cap - op0) L.bail = 1;
+                if ((uint32_t)tid == g1 - 1) {
+                    L.round_start_lo = round_start;
+                    L.round_end_lo = round_start + (exb - bb) + bytes;
+                    L.num_matches = exn - bn + nm;
+                }
+            }
+            WG_SYNC();
+            // every lane takes pieces of kSegSteps steps: piece p of sub-sequence l starts with the totals of
+            // header row p; neighbouring lanes take the same piece of neighbouring sub-sequences (one row, one
+            // contiguous load)
+            if (!L.bail) {
+                const uint32_t G = g1 - g0;
+                bool err = false;
+                for (uint32_t u = tid; u < G * (kTokCap / kSegSteps); u += kT) {
+                    const uint32_t l = g0 + u % G, p = u / G;
+                    const uint32_t steps_l = L.lane_steps[l];
+                    if (p * kSegSteps >= steps_l) continue;
+                    const uint32_t nslot = min(kSegSteps, steps_l - p * kSegSteps);
+                    const uint32_t *col = rows + (kHdrRows + p * kSegSteps) * kT + l;
+                    uint32_t t16[kSegSteps];
+#pragma unroll
+                    for (uint32_t j = 0; j < kSegSteps; j++) t16[j] = j < nslot ? col[j * kT] : kNoTok;
+                    const uint32_t before = p ? rows[p * kT + l] : 0u;
+                    uint32_t op = round_start + (L.lane_at[l] - bb) + (before & 0xFFFF);
+                    uint32_t mi = L.lane_mi[l] - bn + (before >> 16);
+#pragma unroll
+                    for (uint32_t j = 0; j < kSegSteps; j++) {
+                        const uint32_t t = t16[j];
+                        if (t == kNoTok) continue;
+                        if ((int32_t)t < 0) {
+                            const uint32_t len = (t & 0xFF) + 3, d1 = (t >> 8) & 0x7FFF;
+                            err = err || d1 >= op;   // the distance reaches in front of the output
+                            L.mq.dst[mi] = (uint16_t)(op - round_start);
+                            L.ring[(op + c.shift) & kRingMask] = (uint8_t)d1;
+                            L.ring[(op + c.shift + 1) & kRingMask] = (uint8_t)(d1 >> 8);
+                            L.ring[(op + c.shift + 2) & kRingMask] = (uint8_t)(len - 3);
+                            op += len;
+                            mi++;
+                        } else {
+                            L.ring[(op + c.shift) & kRingMask] = (uint8_t)t;
+                            op++;
+                        }
+                    }
+                }
+                if (err) L.bail = 1;
+            }
+            WG_SYNC();
+            if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(9, t - tb); tb = t; }
+            if (L.bail) {
+                bail = true;
+                break;
+            }
+            copy_round(L, c);
+            if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(10, t - tb); tb = t; }
+            pos = L.round_end_lo;
+            flush_upto(pos);
+            WG_SYNC();
+            if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(11, t - tb); tb = t; }
+            g0 = g1;
+        }
+    }
+    if (!bail) flush_range(L, c, flushed, pos);
+    if (tid == 0) {
+        status[item] = bail ? kStatusFallback : RSX_SUCCESS;
+        out_sizes[item] = bail ? 0 : pos;
+    }
+}
+
 // zlib / gzip trailer check (src/decompress/mod.rs:1104-1120, :1202-1233): the
 // checksum of the produced bytes must match the stored one (and ISIZE for gzip).
 __global__ void verify_trailer_kernel(int format, const uint8_t *__restrict__ in,
@@ -1434,42 +2036,58 @@ __global__ void verify_trailer_kernel(int format, const uint8_t *__restrict__ in
 
 }  // namespace
 
-size_t inflate_ws_bytes(size_t n, uint64_t total_out)
+static size_t inflate_common_ws_bytes(size_t n, uint64_t total_out)
 {
     return align_up(n * sizeof(uint64_t), 256) + align_up(n * sizeof(uint32_t), 256) +
            checksum_ws_bytes(n, total_out) + 1024;
 }
 
+size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool split)
+{
+    size_t b = inflate_common_ws_bytes(n, total_out);
+    if (split)
+        b += align_up(split_tok_rows(n, total_in) * kT * sizeof(uint32_t), 256) +
+             align_up(split_round_recs(n, total_in) * sizeof(RoundRec), 256);
+    return b;
+}
+
 int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off, size_t n,
                    uint64_t total_in, uint64_t total_out, uint64_t max_out, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status)
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split)
 {
     if (n == 0) return RSX_OK;
-    // (output positions are 32-bit in the kernel, and a round adds up to 16 KiB before it is checked)
+    // (output positions are 32-bit in the kernels, and a round adds up to 16 KiB before it is checked)
     if (n > 0x7FFFFFFFull || max_out >= (1ull << 32) - (1ull << 16)) {
         e->err = "batch too large (output slots must be < 4 GiB - 64 KiB, n < 2^31)";
         return RSX_E_INVALID;
     }
     uint64_t *body_end = static_cast<uint64_t *>(ws_take(e, n * sizeof(uint64_t)));
     uint32_t *sums = static_cast<uint32_t *>(ws_take(e, n * sizeof(uint32_t)));
-    if (!body_end || !sums) {
+    SplitLayout lay{nullptr, nullptr};
+    if (split) {
+        lay.tok = static_cast<uint32_t *>(ws_take(e, split_tok_rows(n, total_in) * kT * sizeof(uint32_t)));
+        lay.rounds = static_cast<RoundRec *>(ws_take(e, split_round_recs(n, total_in) * sizeof(RoundRec)));
+    }
+    if (!body_end || !sums || (split && (!lay.tok || !lay.rounds))) {
         e->err = "workspace exhausted";
         return RSX_E_NOMEM;
     }
-    const bool want_stats = getenv("RSX_INFLATE_STATS") != nullptr;
-    unsigned long long *d_stats = nullptr;
-    if (want_stats) {
-        RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
-    }
+    const uint32_t grid = (uint32_t)n;
     (void)hipEventRecord(e->ev_begin, e->stream);
-    if (want_stats)
-        inflate_kernel<true><<<(uint32_t)n, kT, 0, e->stream>>>(
-            format, in, in_off, (uint32_t)n, total_in, out, out_off, out_sizes, status, body_end, d_stats);
-    else
-        inflate_kernel<false><<<(uint32_t)n, kT, 0, e->stream>>>(
-            format, in, in_off, (uint32_t)n, total_in, out, out_off, out_sizes, status, body_end, nullptr);
-    (void)hipEventRecord(e->ev_end, e->stream);
-    if (want_stats) {
+    if (split) {
+        inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay);
+        inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
+                                                          lay);
+        // whatever the two left (damaged streams, slots that are too small, streams that need more
+        // token space than the workspace has) is decoded again by the one-kernel decoder
+        inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
+                                                          status, body_end, nullptr, kStatusFallback);
+    } else if (e->inflate_stats) {
+        unsigned long long *d_stats = nullptr;   // (development aid: allocates and synchronises)
+        RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
+        inflate_kernel<true><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
+                                                         status, body_end, d_stats, 0);
+        (void)hipEventRecord(e->ev_end, e->stream);
         std::vector<unsigned long long> h(n * 12);
         RSX_HIP(e, hipMemcpy(h.data(), d_stats, h.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(d_stats);
@@ -1484,14 +2102,32 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                 (double)sum[10] / n, (double)sum[4] / n, (double)sum[5] / n, (double)sum[3] / n,
                 (double)sum[7] / n, (double)sum[8] / n, (double)sum[9] / n, (double)sum[6] / n,
                 (double)sum[11] / n);
+    } else {
+        inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
+                                                          status, body_end, nullptr, 0);
     }
+    if (split || !e->inflate_stats) (void)hipEventRecord(e->ev_end, e->stream);
+#if RSX_SPLIT_TIMERS
+    if (split) {
+        unsigned long long t[16], z[16] = {0};
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+        RSX_HIP(e, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_split_t), sizeof t));
+        RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_split_t), z, sizeof z));
+        const double d = (double)n;
+        fprintf(stderr, "[rsx split] per stream: decode rounds %.1f passes %.1f cycles: stage %.0f header %.0f warm %.0f scan %.0f "
+                        "passes %.0f tail %.0f | expand groups %.1f cycles: records %.0f walk %.0f copy %.0f flush %.0f\n",
+                t[6] / d, t[7] / d, t[0] / d, t[1] / d, t[2] / d, t[3] / d, t[4] / d, t[5] / d, t[12] / d, t[8] / d, t[9] / d,
+                t[10] / d, t[11] / d);
+    }
+#endif
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
     if (format != RSX_FORMAT_DEFLATE) {
         int kind = format == RSX_FORMAT_GZIP ? RSX_CHECKSUM_CRC32 : RSX_CHECKSUM_ADLER32;
         uint32_t init = format == RSX_FORMAT_GZIP ? 0u : 1u;
-        // failed items have out_sizes 0 and cost nothing
-        int r = checksum_launch(e, kind, init, out, out_off, out_sizes, n, total_out, max_out, sums);
+        // failed items have out_sizes 0 and cost nothing; the slot sizes are the caller's word, so the
+        // segment grid is derived from the produced sizes on the device (trusted_max = false)
+        int r = checksum_launch(e, kind, init, out, out_off, out_sizes, n, total_out, max_out, sums, false);
         if (r != RSX_OK) return r;
         verify_trailer_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, e->stream>>>(
             format, in, in_off, (uint32_t)n, body_end, sums, out_sizes, status);

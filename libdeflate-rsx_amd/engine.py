@@ -44,7 +44,8 @@ class RsxError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "librsx_deflate.so")
+    # RSX_LIBRARY: another build of the same library (kernel tuning experiments)
+    return os.environ.get("RSX_LIBRARY") or os.path.join(_HERE, "lib", "librsx_deflate.so")
 
 
 def load_library():
