@@ -161,6 +161,27 @@ int rsx_batch_checksum_device(rsx_engine *e, int kind, uint32_t init, const uint
                               const uint64_t *in_off, size_t n, uint64_t total_in,
                               uint64_t max_item, uint32_t *values);
 
+/*
+ * rsx_batch_decompress_device for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  Same arguments and
+ * results as rsx_batch_decompress_device; what that call takes from the
+ * engine's grow-only workspace (end-of-stream positions, checksum partials,
+ * trailer sums) lives here in a 1 MiB array that is part of the library's
+ * device code, one copy per GPU, so the call neither allocates nor frees.
+ * Limits: n <= RSX_NOALLOC_MAX_ITEMS and total_out <= RSX_NOALLOC_MAX_TOTAL_OUT,
+ * beyond them the call returns RSX_E_INVALID and does nothing.  All engines on
+ * one GPU share that GPU's array: two such calls that overlap in time on one
+ * GPU (different engines or streams) race; calls on one stream are safe.
+ */
+#define RSX_NOALLOC_MAX_ITEMS 8192
+#define RSX_NOALLOC_MAX_TOTAL_OUT (1ull << 30)
+int rsx_batch_decompress_device_noalloc(rsx_engine *e, int format, const uint8_t *in,
+                                        const uint64_t *in_off, size_t n, uint64_t total_in,
+                                        uint64_t total_out, uint64_t max_out, uint8_t *out,
+                                        const uint64_t *out_off, uint64_t *out_sizes,
+                                        int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

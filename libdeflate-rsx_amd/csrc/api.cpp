@@ -34,6 +34,19 @@ int ws_reserve(rsx_engine *e, size_t bytes)
     return RSX_OK;
 }
 
+int ws_use_static(rsx_engine *e, size_t bytes)
+{
+    e->ws_used = 0;
+    e->arena = e->static_scratch;
+    e->arena_size = e->static_scratch_size;
+    if (!e->static_scratch || bytes > e->static_scratch_size) {
+        e->arena = nullptr;
+        e->arena_size = 0;
+        return RSX_E_INVALID;
+    }
+    return RSX_OK;
+}
+
 void *ws_take(rsx_engine *e, size_t bytes)
 {
     size_t at = align_up(e->ws_used, 256);
@@ -119,7 +132,7 @@ int rsx_engine_create(int device, void *stream, rsx_engine **out)
     }
     hipDeviceProp_t prop;
     if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess ||
-        checksum_tables_create(e) != RSX_OK ||
+        checksum_tables_create(e) != RSX_OK || inflate_static_scratch(e) != RSX_OK ||
         hipGetDeviceProperties(&prop, device) != hipSuccess) {
         rsx_engine_destroy(e);
         return RSX_E_DEVICE;
@@ -209,6 +222,29 @@ int rsx_batch_decompress_device(rsx_engine *e, int format, const uint8_t *in,
     if (r != RSX_OK) return r;
     return inflate_launch(e, format, in, in_off, n, total_in, total_out, max_out, out, out_off,
                           out_sizes, status, e->inflate_split);
+}
+
+int rsx_batch_decompress_device_noalloc(rsx_engine *e, int format, const uint8_t *in,
+                                        const uint64_t *in_off, size_t n, uint64_t total_in,
+                                        uint64_t total_out, uint64_t max_out, uint8_t *out,
+                                        const uint64_t *out_off, uint64_t *out_sizes, int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (!format_ok(format)) return bad(e, "bad format");
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    if (n > RSX_NOALLOC_MAX_ITEMS || total_out > RSX_NOALLOC_MAX_TOTAL_OUT)
+        return bad(e, "batch too large for the static scratch (n <= 8192 items, total_out <= 1 GiB)");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    // the one-kernel decoder: its scratch (16 bytes per item and the checksum partials) fits the
+    // static array; the token arrays of the two-kernel decoder do not
+    if (ws_use_static(e, inflate_ws_bytes(n, total_in, total_out, false)) != RSX_OK) {
+        e->err = "static scratch too small for this batch";
+        return RSX_E_INVALID;
+    }
+    return inflate_launch(e, format, in, in_off, n, total_in, total_out, max_out, out, out_off,
+                          out_sizes, status, false);
 }
 
 int rsx_batch_compress_device(rsx_engine *e, int format, int level, const uint8_t *in,

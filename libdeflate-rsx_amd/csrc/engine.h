@@ -18,12 +18,18 @@ struct rsx_engine {
     std::mutex mu;
     std::string err;
 
-    // grow-only device workspace (ws), carved per call by ws_take() from the arena the call selected
+    // grow-only device workspace (ws), carved per call by ws_take() from the arena the call
+    // selected: the workspace (ws_reserve) or this device's static scratch (ws_use_static)
     uint8_t *ws = nullptr;
     size_t ws_size = 0;
     uint8_t *arena = nullptr;
     size_t arena_size = 0;
     size_t ws_used = 0;
+
+    // device address of the static scratch array of inflate.hip on this engine's GPU
+    // (hipGetSymbolAddress at engine creation); shared by every engine on that GPU
+    uint8_t *static_scratch = nullptr;
+    size_t static_scratch_size = 0;
 
     int num_cus = 0;           // multiprocessors of this engine's GPU
     bool inflate_stats = false;  // RSX_INFLATE_STATS was set when the engine was created
@@ -47,6 +53,8 @@ struct rsx_engine {
 
 // Ensures the workspace holds at least `bytes`, makes it the arena and resets the carve pointer.
 int ws_reserve(rsx_engine *e, size_t bytes);
+// Makes the device's static scratch the arena (no allocation); RSX_E_INVALID if `bytes` exceed it.
+int ws_use_static(rsx_engine *e, size_t bytes);
 // Carves `bytes` (256-byte aligned) out of the arena; nullptr if exhausted.
 void *ws_take(rsx_engine *e, size_t bytes);
 
@@ -72,6 +80,8 @@ int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
                     uint64_t max_item, uint32_t *values, bool trusted_max);
 
 // inflate.hip
+// looks up this GPU's copy of the static scratch array (call with the engine's device current)
+int inflate_static_scratch(rsx_engine *e);
 // split: the two-kernel decoder (tokens in the workspace) with the one-kernel decoder for what it leaves;
 // otherwise the one-kernel decoder alone (small workspace)
 size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool split);

@@ -2034,7 +2034,22 @@ __global__ void verify_trailer_kernel(int format, const uint8_t *__restrict__ in
     }
 }
 
+// Scratch of rsx_batch_decompress_device_noalloc: every GPU the library runs on holds its own copy
+// of this array until the process ends; host code reaches it only through the address that
+// inflate_static_scratch() looks up.
+constexpr size_t kStaticScratchBytes = 1u << 20;
+static __device__ __align__(256) uint8_t scratch[kStaticScratchBytes];
+
 }  // namespace
+
+int inflate_static_scratch(rsx_engine *e)
+{
+    void *ptr = nullptr;
+    RSX_HIP(e, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    e->static_scratch = static_cast<uint8_t *>(ptr);
+    e->static_scratch_size = kStaticScratchBytes;
+    return RSX_OK;
+}
 
 static size_t inflate_common_ws_bytes(size_t n, uint64_t total_out)
 {

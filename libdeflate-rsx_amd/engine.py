@@ -36,7 +36,11 @@ SYMBOLS = [
      [_P, C.c_int, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     ("rsx_batch_checksum_device", C.c_int,
      [_P, C.c_int, C.c_uint32, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P]),
+    ("rsx_batch_decompress_device_noalloc", C.c_int,
+     [_P, C.c_int, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
 ]
+NOALLOC_MAX_ITEMS = 8192
+NOALLOC_MAX_TOTAL_OUT = 1 << 30
 
 
 class RsxError(RuntimeError):
@@ -190,6 +194,13 @@ class Engine:
         self._check(self._lib.rsx_batch_decompress_device(self._h, fmt, d_in, d_in_off, n, total_in,
                                                           total_out, max_out, d_out, d_out_off,
                                                           d_sizes, d_status))
+
+    def batch_decompress_device_noalloc(self, fmt, d_in, d_in_off, n, total_in, total_out, max_out, d_out,
+                                        d_out_off, d_sizes, d_status):
+        """rsx_batch_decompress_device without any device allocation (static scratch; see the header)"""
+        self._check(self._lib.rsx_batch_decompress_device_noalloc(self._h, fmt, d_in, d_in_off, n, total_in,
+                                                                  total_out, max_out, d_out, d_out_off,
+                                                                  d_sizes, d_status))
 
     def batch_compress_device(self, fmt, level, d_in, d_in_off, n, total_in, max_item, d_out, d_out_off,
                               d_sizes, d_status):
