@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: batch gzip decompress of 4096 x 1 MiB level-6 text
-buffers per GPU (BASELINE.json configs[1]), reported as GiB/s of bytes in + out.
+buffers per GPU (BASELINE.json configs[1]), reported as GiB/s of bytes in + out,
+with the compress half of the metric (configs[2]: zlib level 6, 4096 x 1 MiB
+mixed text/binary) attached to the same JSON line as "secondary".
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  Streams are independent, so ranks shard the batch with no
-data-path collective (weak scaling: every rank decodes its own 4096 streams);
-RCCL is used only for the start/stop barrier and the max-over-ranks reduce.
+`--gpus N` from a bare shell (no WORLD_SIZE in the environment) starts the N
+ranks itself, before anything in this process has touched the GPU, and relays
+rank 0's JSON line.  One process per GPU.
 
-A step = one rsx_batch_decompress_device call over the whole per-rank batch,
+Streams are independent, so ranks shard the work with no data-path collective;
+RCCL carries the start/stop barrier, the max-over-ranks time and, in the
+sharded modes, the gather of per-item sizes and status.
+  --scaling weak   (default) every rank decodes its own 4096 streams;
+  --scaling strong ONE logical batch (default: BASELINE.json configs[3], 65536 x
+                   64 KiB gzip) is partitioned over the ranks by
+                   libdeflate-rsx_amd/sharding.py, every rank decodes its range and
+                   the u64 sizes + i32 status are all_gathered on the GPUs.
+
+A step = one rsx_batch_decompress_device call over the rank's whole batch,
 inputs and outputs resident in HBM.  The compressed streams are produced by the
-CPU restatement of the reference compressor (gzip, level 6, four sync-flushed
-256 KiB segments per buffer); `--distinct` different buffers are generated and
-physically replicated in device memory to the full batch so every stream is
-read from its own addresses.
+CPU restatement of the reference compressor (gzip, level 6, sync-flushed 256 KiB
+segments); `--distinct` different buffers are generated and physically
+replicated in device memory to the full batch so every stream is read from its
+own addresses.  Every output row is compared with its source on the device,
+outside the timed region.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,10 +42,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+METRIC = "batch GiB/s in+out (compress@L6, decompress) at 1/2/4/8 GPUs; % HBM roofline"
 
 
 def measured_traffic(key):
-    """HBM bytes per launch of the dominant kernel for the default workloads, taken from
+    """HBM bytes per launch of the dominant kernels for the default workloads, taken from
     separate rocprofv3 --pmc passes (counters cannot be collected inside a timed run);
     None for any other configuration."""
     try:
@@ -50,6 +64,20 @@ def host_threads():
     return max(1, min(avail, 16))  # a 1-GPU box shares 16 host cores
 
 
+def self_launch(args, argv):
+    """--gpus N without a launcher: start N ranks under torch.distributed.run as a child of this
+    process (which has not touched the GPU) and pass their output and exit code on."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def make_streams(distinct, buf_bytes, fmt, level, seed0):
     import corpus
     import oracle_lib as orc
@@ -62,7 +90,7 @@ def make_streams(distinct, buf_bytes, fmt, level, seed0):
     return texts, streams
 
 
-def cpu_baseline(streams, buf_bytes, fmt, target_s=12.0):
+def cpu_decompress_baseline(streams, buf_bytes, fmt, target_s=12.0):
     """Times the CPU restatement of the reference decoder on the distinct streams
     (all host threads the box grants), repeated until ~target_s of work."""
     import oracle_lib as orc
@@ -83,15 +111,174 @@ def cpu_baseline(streams, buf_bytes, fmt, target_s=12.0):
             break
     assert (status == 0).all()
     nbytes = reps * (int(in_off[-1]) + int(sizes.sum()))
-    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": th, "kind": "port",
-            "sample": "%d x %d distinct streams of the same workload, %d passes, %.1f s"
-                      % (reps, d, reps, dt)}
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": th,
+            "kind": "port",
+            "note": "C restatement of the reference decoder's careful loop (byte-serial match copy), not its BMI2 "
+                    "fast loop: a lower bound of the reference's CPU rate",
+            "sample": "%d x %d distinct streams of the same workload, %d passes, %.1f s" % (reps, d, reps, dt)}
 
 
-def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
-    """BASELINE.json configs[2]: batch zlib compress level 6, n x 1 MiB mixed text/binary."""
+class Ctx:
+    """torch, torch.distributed, the engine package and this rank's place in the job."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        import rsx_pkg
+        self.torch, self.dist, self.rsx = torch, dist, rsx_pkg.load()
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+        # RSX_BENCH_REHEARSE=1: a rehearsal of the multi-rank path on a box with fewer GPUs than ranks --
+        # ranks share the GPUs that exist and the collectives run over gloo.  Not a measurement.
+        self.rehearse = os.environ.get("RSX_BENCH_REHEARSE") == "1"
+        if self.rehearse:
+            self.local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+        self.reduce_device = torch.device("cpu") if self.rehearse else self.dev
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.eng = self.rsx.Engine(self.local_rank, self.stream.cuda_stream)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.reduce_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        if self.world == 1:
+            return int(value)
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.reduce_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+
+def timed_steps(ctx, step, steps, warmup):
+    """W untimed steps, then exactly K steps between two barrier + synchronize pairs; a third
+    loop reads the per-launch kernel time so that reading events never serialises the timed one."""
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = []
+    for _ in range(steps):
+        step()
+        kernel_ms.append(ctx.eng.last_kernel_ms())
+    ctx.torch.cuda.synchronize(ctx.dev)
+    return ctx.max_over_ranks(dt), float(np.mean(kernel_ms))
+
+
+def device_batch(ctx, streams, idx):
+    """Device copies of the streams idx[0], idx[1], ... (indices into `streams`), flat + offsets."""
+    torch = ctx.torch
+    lens = np.array([len(streams[i]) for i in idx], dtype=np.uint64)
+    in_off = np.zeros(len(idx) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=in_off[1:])
+    h_in = np.empty(int(in_off[-1]), dtype=np.uint8)
+    for k, i in enumerate(idx):
+        h_in[int(in_off[k]):int(in_off[k + 1])] = streams[i]
+    return torch.from_numpy(h_in).to(ctx.dev), torch.from_numpy(in_off.view(np.int64)).to(ctx.dev), in_off
+
+
+def verify_rows(ctx, d_out, n, buf, texts, idx, d_status, d_sizes):
+    """Every status 0, every size exact and every output row equal to its source, compared on the device."""
+    torch = ctx.torch
+    st = d_status.cpu().numpy()
+    sz = d_sizes.cpu().numpy()
+    ok = bool((st == 0).all() and (sz == buf).all())
+    want = torch.from_numpy(np.frombuffer(b"".join(texts), dtype=np.uint8).copy()).to(ctx.dev).view(len(texts), buf)
+    rows = d_out.view(n, buf)
+    sel = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(ctx.dev)
+    bad_rows = []
+    for a in range(0, n, 512):   # (pieces: the comparison needs a gathered copy of the sources)
+        z = min(n, a + 512)
+        eq = (rows[a:z] == want[sel[a:z]]).all(dim=1)
+        if not bool(eq.all()):
+            bad_rows += [a + int(k) for k in torch.nonzero(~eq).flatten().cpu().numpy()[:8]]
+    if not ok or bad_rows:
+        bad = np.nonzero((st != 0) | (sz != buf))[0]
+        raise SystemExit("bench.py: GPU output does not match the input texts (status values %s, %d streams with a "
+                         "bad status or size, first %s; rows that differ: %s)"
+                         % (np.unique(st), len(bad), bad[:8], bad_rows[:8]))
+    return True
+
+
+def bench_decompress(args, ctx):
+    """BASELINE.json configs[1]: batch gzip decompress, n x 1 MiB level-6 text per GPU (weak scaling)."""
+    rsx = ctx.rsx
+    fmt, level = rsx.FORMAT_GZIP, 6
+    buf = args.buf_kib * 1024
+    n = args.streams
+    distinct = min(args.distinct, n)
+    texts, streams = make_streams(distinct, buf, fmt, level, seed0=1000 * ctx.rank)
+    idx = [i % distinct for i in range(n)]   # stream i is a private copy of distinct stream i % distinct
+    d_in, d_in_off, in_off = device_batch(ctx, streams, idx)
+    total_in, total_out = int(in_off[-1]), n * buf
+    torch = ctx.torch
+    d_out_off = torch.from_numpy((np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)).view(np.int64)).to(ctx.dev)
+    d_out = torch.empty(total_out, dtype=torch.uint8, device=ctx.dev)
+    d_sizes = torch.zeros(n, dtype=torch.int64, device=ctx.dev)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=ctx.dev)
+
+    def step():
+        ctx.eng.batch_decompress_device(fmt, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, total_out,
+                                        buf, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                        d_status.data_ptr())
+
+    dt, k_ms = timed_steps(ctx, step, args.steps, args.warmup)
+    ok = verify_rows(ctx, d_out, n, buf, texts, idx, d_status, d_sizes)
+    job_bytes = ctx.sum_over_ranks(total_in + total_out)
+    alg_bytes = total_in + total_out   # per launch on this rank
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    res = {
+        "value": job_bytes * args.steps / dt / 2**30, "unit": "GiB/s", "ms_per_step": dt / args.steps * 1e3,
+        "scaling": "weak",
+        "config": {
+            "workload": "batch gzip decompress, %d x %d KiB level-6 enwik-style text per GPU" % (n, args.buf_kib),
+            "op": "decompress", "format": "gzip", "level": level, "streams_per_gpu": n,
+            "buf_bytes": buf, "distinct_buffers": distinct, "compressed_ratio": total_out / total_in,
+            "compressor": "CPU restatement of the reference, 256 KiB sync-flushed segments",
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective" % ctx.world,
+            "verified": ok, "verified_rows": n,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level)),
+            "kernel": "inflate_decode_kernel + inflate_expand_kernel (two dependent launches, timed together)",
+            "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+        },
+    }
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_decompress_baseline(streams, buf, fmt)
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_compress(args, ctx):
+    """BASELINE.json configs[2]: batch zlib compress level 6, n x 1 MiB mixed text/binary per GPU."""
     import corpus
     import oracle_lib as orc
+    rsx, torch = ctx.rsx, ctx.torch
     level = args.level
     fmt = rsx.FORMAT_ZLIB if args.corpus == "mixed" else rsx.FORMAT_DEFLATE
     ofmt = orc.FMT_ZLIB if args.corpus == "mixed" else orc.FMT_DEFLATE
@@ -100,44 +287,26 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     n = args.streams
     distinct = min(args.distinct, n)
     gen = {"mixed": corpus.mixed, "json": corpus.json_like, "text": corpus.text}[args.corpus]
-    datas = [gen(buf, 1000 * rank + i) for i in range(distinct)]
+    datas = [gen(buf, 1000 * ctx.rank + i) for i in range(distinct)]
     h_in = np.frombuffer(b"".join(datas), dtype=np.uint8)
-    d_one = torch.from_numpy(h_in.copy()).to(dev)
+    d_one = torch.from_numpy(h_in.copy()).to(ctx.dev)
     d_in = d_one.repeat(n // distinct + 1)[: n * buf].contiguous()  # private copy per item
     in_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)
     bound = int(rsx.compress_bound(fmt, buf))
     out_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(bound)
-    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
-    d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
-    d_out = torch.zeros(n * bound, dtype=torch.uint8, device=dev)
-    d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
-    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
-    eng = rsx.Engine(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(ctx.dev)
+    d_out_off = torch.from_numpy(out_off.view(np.int64)).to(ctx.dev)
+    d_out = torch.zeros(n * bound, dtype=torch.uint8, device=ctx.dev)
+    d_sizes = torch.zeros(n, dtype=torch.int64, device=ctx.dev)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=ctx.dev)
     total_in = n * buf
 
     def step():
-        eng.batch_compress_device(fmt, level, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, buf,
-                                  d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
-                                  d_status.data_ptr())
+        ctx.eng.batch_compress_device(fmt, level, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, buf,
+                                      d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                      d_status.data_ptr())
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = []
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(eng.last_kernel_ms())
-    torch.cuda.synchronize(dev)
+    dt, k_ms = timed_steps(ctx, step, args.steps, args.warmup)
     st = d_status.cpu().numpy()
     sz = d_sizes.cpu().numpy()
     ok = bool((st == 0).all())
@@ -152,54 +321,110 @@ def bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev):
     if not ok:
         raise SystemExit("bench.py: compressed output failed verification")
     total_out = int(sz.sum())
-    job_bytes = total_in + total_out
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=args.reduce_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        b = torch.tensor([job_bytes], dtype=torch.int64, device=args.reduce_device)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        job_bytes = int(b.item())
-    if rank == 0:
-        k_ms = float(np.mean(kernel_ms))
-        achieved = (total_in + total_out) / (k_ms * 1e-3) / 1e9
-        res = {
-            "metric": "batch GiB/s in+out (compress@L6, decompress) at 1/2/4/8 GPUs; % HBM roofline",
-            "value": job_bytes * args.steps / dt / 2**30, "unit": "GiB/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "batch %s compress level %d, %d x %d KiB %s per GPU"
-                                   % (fmt_name, level, n, args.buf_kib,
-                                      {"mixed": "mixed text/binary", "json": "JSON", "text": "text"}[args.corpus]),
-                       "op": "compress", "format": fmt_name, "level": level, "streams_per_gpu": n,
-                       "buf_bytes": buf, "distinct_buffers": distinct,
-                       "compressed_ratio": total_in / total_out, "verified": ok},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level)),
-                         "kernel": "deflate_chunks_kernel", "kernel_ms": k_ms,
-                         "algorithmic_bytes": total_in + total_out},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            th = host_threads()
-            flat = np.frombuffer(b"".join(datas), dtype=np.uint8)
-            off = np.arange(distinct + 1, dtype=np.uint64) * np.uint64(buf)
-            t1 = time.perf_counter()
-            reps = 0
-            while True:
-                _, _, csz, cst = orc.batch_compress(flat, off, ofmt, level, threads=th)
-                reps += 1
-                cdt = time.perf_counter() - t1
-                if cdt >= 12.0:
-                    break
-            res["cpu_baseline"] = {"value": reps * (distinct * buf + int(csz.sum())) / cdt / 2**30,
-                                   "unit": "GiB/s", "cores": th, "kind": "port",
-                                   "sample": "%d passes over %d distinct buffers, %.1f s" % (reps, distinct, cdt),
-                                   "compressed_ratio": distinct * buf / float(csz.sum())}
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    job_bytes = ctx.sum_over_ranks(total_in + total_out)
+    achieved = (total_in + total_out) / (k_ms * 1e-3) / 1e9
+    res = {
+        "value": job_bytes * args.steps / dt / 2**30, "unit": "GiB/s", "ms_per_step": dt / args.steps * 1e3,
+        "scaling": "weak",
+        "config": {"workload": "batch %s compress level %d, %d x %d KiB %s per GPU"
+                               % (fmt_name, level, n, args.buf_kib,
+                                  {"mixed": "mixed text/binary", "json": "JSON", "text": "text"}[args.corpus]),
+                   "op": "compress", "format": fmt_name, "level": level, "streams_per_gpu": n,
+                   "buf_bytes": buf, "distinct_buffers": distinct,
+                   "compressed_ratio": total_in / total_out, "verified": ok},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level)),
+                     "kernel": "deflate_chunks_kernel", "kernel_ms": k_ms,
+                     "algorithmic_bytes": total_in + total_out},
+    }
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        th = host_threads()
+        flat = np.frombuffer(b"".join(datas), dtype=np.uint8)
+        off = np.arange(distinct + 1, dtype=np.uint64) * np.uint64(buf)
+        t1 = time.perf_counter()
+        reps = 0
+        while True:
+            _, _, csz, cst = orc.batch_compress(flat, off, ofmt, level, threads=th)
+            reps += 1
+            cdt = time.perf_counter() - t1
+            if cdt >= 12.0:
+                break
+        res["cpu_baseline"] = {"value": reps * (distinct * buf + int(csz.sum())) / cdt / 2**30,
+                               "unit": "GiB/s", "cores": th, "kind": "port",
+                               "note": "C restatement of the reference compressor (scalar match-length loop)",
+                               "sample": "%d passes over %d distinct buffers, %.1f s" % (reps, distinct, cdt),
+                               "compressed_ratio": distinct * buf / float(csz.sum())}
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_strong(args, ctx):
+    """BASELINE.json configs[3]: ONE logical batch of gzip streams (default 65536 x 64 KiB) spread over the
+    ranks: partition by compressed bytes, every rank decodes its range, sizes and status are gathered on
+    the GPUs (RCCL), three totals are all-reduced.  The total work is fixed as N grows."""
+    from libdeflate_rsx_amd import sharding
+    rsx, torch = ctx.rsx, ctx.torch
+    fmt, level = rsx.FORMAT_GZIP, 6
+    buf = args.buf_kib * 1024
+    n_total = args.streams
+    distinct = min(args.distinct, n_total)
+    texts, streams = make_streams(distinct, buf, fmt, level, seed0=7000)   # the same logical batch on every rank
+    lens_all = np.array([len(streams[i % distinct]) for i in range(n_total)], dtype=np.int64)
+    ranges = sharding.partition(lens_all, ctx.world)
+    s, e = ranges[ctx.rank]
+    n = e - s
+    idx = [i % distinct for i in range(s, e)]
+    d_in, d_in_off, in_off = device_batch(ctx, streams, idx)
+    total_in, total_out = int(in_off[-1]), n * buf
+    d_out_off = torch.from_numpy((np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)).view(np.int64)).to(ctx.dev)
+    d_out = torch.empty(max(total_out, 1), dtype=torch.uint8, device=ctx.dev)
+    d_sizes = torch.zeros(max(n, 1), dtype=torch.int64, device=ctx.dev)
+    d_status = torch.full((max(n, 1),), -7, dtype=torch.int32, device=ctx.dev)
+    gathered = {}
+
+    def step():
+        if n:
+            ctx.eng.batch_decompress_device(fmt, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, total_out,
+                                            buf, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                            d_status.data_ptr())
+        # the exchange step of the path: sizes + status of the whole batch on every rank, three totals
+        if ctx.rehearse:
+            ctx.torch.cuda.synchronize(ctx.dev)
+        gathered["r"] = sharding.gather_results(d_sizes[:n], d_status[:n], ranges,
+                                                ctx.dist if ctx.world > 1 else None, total_in=total_in)
+
+    dt, k_ms = timed_steps(ctx, step, args.steps, args.warmup)
+    if n:
+        verify_rows(ctx, d_out[:total_out], n, buf, texts, idx, d_status[:n], d_sizes[:n])
+    all_sizes, all_status, totals = gathered["r"]
+    ok = bool((all_status == 0).all() and (all_sizes == buf).all() and len(all_sizes) == n_total
+              and totals == (int(lens_all.sum()), n_total * buf, 0))
+    if not ok:
+        raise SystemExit("bench.py: gathered sizes / status / totals of the sharded batch are wrong: %s" % (totals,))
+    job_bytes = totals[0] + totals[1]
+    alg_bytes = total_in + total_out
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if n else 0.0
+    return {
+        "value": job_bytes * args.steps / dt / 2**30, "unit": "GiB/s", "ms_per_step": dt / args.steps * 1e3,
+        "scaling": "strong",
+        "config": {
+            "workload": "one batch of %d x %d KiB gzip level-6 text streams sharded over %d GPU(s), sizes/status "
+                        "gathered over RCCL" % (n_total, args.buf_kib, ctx.world),
+            "op": "decompress", "format": "gzip", "level": level, "streams_total": n_total,
+            "streams_this_rank": n, "buf_bytes": buf, "distinct_buffers": distinct,
+            "compressed_ratio": n_total * buf / float(lens_all.sum()),
+            "parallelism": "contiguous ranges balanced by compressed bytes; all_gather(u64 sizes, i32 status) + "
+                           "all_reduce(3 x i64) per step", "verified": ok, "verified_rows": n,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": "inflate_decode_kernel + inflate_expand_kernel (two dependent launches, timed together)",
+            "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+        },
+    }
 
 
 def main():
@@ -207,174 +432,54 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
-    ap.add_argument("--buf-kib", type=int, default=1024, help="uncompressed KiB per stream")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="streams per GPU (weak scaling, default 4096) or in the whole batch (strong, default 65536)")
+    ap.add_argument("--buf-kib", type=int, default=None, help="uncompressed KiB per stream (1024; strong: 64)")
     ap.add_argument("--distinct", type=int, default=64, help="distinct buffers generated on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the compress leg of the default run")
     ap.add_argument("--level", type=int, default=6, help="compress only")
     ap.add_argument("--corpus", choices=["mixed", "json", "text"], default="mixed",
                     help="compress only: mixed = zlib (headline), json/text = raw deflate")
     ap.add_argument("--op", choices=["decompress", "compress"], default="decompress",
-                    help="decompress = gzip level-6 text (headline); compress = zlib level-6 mixed")
-    args = ap.parse_args()
+                    help="decompress = gzip level-6 text (headline) with the compress leg attached; "
+                         "compress = zlib level-6 mixed alone")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    argv = sys.argv[1:]
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    strong = args.scaling == "strong"
+    if args.streams is None:
+        args.streams = 65536 if strong else 4096
+    if args.buf_kib is None:
+        args.buf_kib = 64 if strong else 1024
 
-    import torch
-    import torch.distributed as dist
-    import rsx_pkg
-    rsx = rsx_pkg.load()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # RSX_BENCH_REHEARSE=1: a rehearsal of the multi-rank path on a box with fewer GPUs than ranks --
-    # ranks share the GPUs that exist and the two reductions run over gloo.  Not a measurement.
-    rehearse = os.environ.get("RSX_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-    args.reduce_device = torch.device("cpu") if rehearse else dev
-
-    if args.op == "compress":
-        return bench_compress(args, rsx, torch, dist, rank, local_rank, world, dev)
-    fmt, level = rsx.FORMAT_GZIP, 6
-    buf = args.buf_kib * 1024
-    n = args.streams
-    distinct = min(args.distinct, n)
-    texts, streams = make_streams(distinct, buf, fmt, level, seed0=1000 * rank)
-
-    # replicate to the full batch: stream i is a private copy of distinct stream i % distinct
-    lens = np.array([len(streams[i % distinct]) for i in range(n)], dtype=np.uint64)
-    in_off = np.zeros(n + 1, dtype=np.uint64)
-    np.cumsum(lens, out=in_off[1:])
-    total_in = int(in_off[-1])
-    h_in = np.empty(total_in, dtype=np.uint8)
-    for i in range(n):
-        h_in[int(in_off[i]):int(in_off[i + 1])] = streams[i % distinct]
-    out_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)
-    total_out = n * buf
-
-    d_in = torch.from_numpy(h_in).to(dev)
-    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
-    d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
-    d_out = torch.empty(total_out, dtype=torch.uint8, device=dev)
-    d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
-    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
-    del h_in
-
-    stream = torch.cuda.current_stream(dev)
-    eng = rsx.Engine(local_rank, stream.cuda_stream)
-
-    def step():
-        eng.batch_decompress_device(fmt, d_in.data_ptr(), d_in_off.data_ptr(), n, total_in, total_out,
-                                    buf, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
-                                    d_status.data_ptr())
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(None)
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-launch kernel time: a second, separately timed loop so reading the
-    # events does not serialise the timed region above
-    for k in range(args.steps):
-        step()
-        kernel_ms[k] = eng.last_kernel_ms()
-    torch.cuda.synchronize(dev)
-
-    # verification outside the timed region: every status 0, sizes exact, and the
-    # first `distinct` outputs byte-identical to the original texts
-    st = d_status.cpu().numpy()
-    sz = d_sizes.cpu().numpy()
-    ok = bool((st == 0).all() and (sz == buf).all())
-    host_out = d_out[: distinct * buf].cpu().numpy()
-    for i in range(distinct):
-        ok = ok and host_out[i * buf:(i + 1) * buf].tobytes() == texts[i]
-    if not ok:
-        bad = np.nonzero((st != 0) | (sz != buf))[0]
-        for i in bad[:6]:   # where the output of a failed stream first departs from its text
-            got = d_out[int(i) * buf:(int(i) + 1) * buf].cpu().numpy()
-            want = np.frombuffer(texts[int(i) % distinct], dtype=np.uint8)
-            diff = np.nonzero(got != want)[0]
-            p0 = int(diff[0]) if len(diff) else -1
-            shift = [k for k in range(1, 64) if p0 >= 0 and p0 + k + 64 <= buf
-                     and (got[p0 + k:p0 + k + 64] == want[p0:p0 + 64]).all()]
-            if p0 >= 0:
-                print("[bench]   want %r" % want[max(0, p0 - 24):p0 + 72].tobytes(), file=sys.stderr)
-                print("[bench]   got  %r" % got[max(0, p0 - 24):p0 + 72].tobytes(), file=sys.stderr)
-            print("[bench] stream %d status %d first mismatch at %d (%d differing bytes), "
-                  "output continues the text after an insertion of %s bytes"
-                  % (i, st[i], p0, len(diff), shift[:1] or "?"), file=sys.stderr)
-        raise SystemExit("bench.py: GPU output does not match the input texts (status values %s, %d bad "
-                         "streams, first %s, their status %s sizes %s)"
-                         % (np.unique(st), len(bad), bad[:8], st[bad[:8]], sz[bad[:8]]))
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=args.reduce_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        b = torch.tensor([total_in + total_out], dtype=torch.int64, device=args.reduce_device)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        job_bytes = int(b.item())
+    ctx = Ctx(args)
+    if strong:
+        res = bench_strong(args, ctx)
+    elif args.op == "compress":
+        res = bench_compress(args, ctx)
     else:
-        job_bytes = total_in + total_out
-
-    if rank == 0:
-        alg_bytes = total_in + total_out  # per launch on this rank
-        k_ms = float(np.mean(kernel_ms))
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        res = {
-            "metric": "batch GiB/s in+out (compress@L6, decompress) at 1/2/4/8 GPUs; % HBM roofline",
-            "value": job_bytes * args.steps / dt / 2**30,
-            "unit": "GiB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": "batch gzip decompress, %d x %d KiB level-6 enwik-style text per GPU"
-                            % (n, args.buf_kib),
-                "op": "decompress", "format": "gzip", "level": level, "streams_per_gpu": n,
-                "buf_bytes": buf, "distinct_buffers": distinct,
-                "compressed_ratio": total_out / total_in,
-                "compressor": "CPU restatement of the reference, 256 KiB sync-flushed segments",
-                "parallelism": "batch sharded over %d GPU(s), no data-path collective" % world,
-                "verified": ok,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level)),
-                "kernel": "inflate_kernel", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(streams, buf, fmt)
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        res = bench_decompress(args, ctx)
+        if not args.no_secondary:
+            sec = bench_compress(args, ctx)
+            res["secondary"] = {"metric": METRIC, "value": sec["value"], "unit": sec["unit"],
+                                "ms_per_step": sec["ms_per_step"], "config": sec["config"],
+                                "roofline": sec["roofline"]}
+            if "cpu_baseline" in sec:
+                res["secondary"]["cpu_baseline"] = sec["cpu_baseline"]
+    if ctx.rank == 0:
+        line = {"metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": ctx.world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "u8",
+                "data": "synthetic"}
+        for k in ("config", "roofline", "cpu_baseline", "secondary"):
+            if k in res:
+                line[k] = res[k]
+        print(json.dumps(line), flush=True)
+    if ctx.world > 1:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -176,3 +176,24 @@ def test_understated_longest_item_never_overruns(eng, rsx):
             c = out[int(out_off[i]):int(out_off[i]) + int(sz[i])].tobytes()
             assert zlib.decompress(c, -15) == d
     assert st[0] == 0 and st[2] == 0
+
+
+def test_run_sharded_with_the_engine_matches_the_unsharded_call(eng, rsx):
+    # the multi-rank path at world size 1 with the engine as the per-rank compute: the same
+    # function the two-rank gloo test drives, byte for byte against one plain call
+    from libdeflate_rsx_amd.sharding import run_sharded
+    texts = [corpus.text(30000 + 7000 * i, 70 + i) for i in range(12)] + [b""]
+    streams = [o.compress(t, 6, 2) for t in texts]
+    streams[5] = streams[5][:-2]   # a damaged item stays one item's failure
+
+    def local(sub, s, e):
+        res, st = eng.batch_decompress(sub, [len(t) for t in texts[s:e]], rsx.FORMAT_GZIP)
+        sizes = np.array([len(r) if r is not None else 0 for r in res], dtype=np.int64)
+        return res, sizes, st
+
+    (s, e), res, all_sizes, all_status, totals = run_sharded(streams, [len(c) for c in streams], local, None)
+    plain, plain_st = eng.batch_decompress(streams, [len(t) for t in texts], rsx.FORMAT_GZIP)
+    assert (s, e) == (0, len(texts)) and res == plain
+    assert (np.asarray(all_status) == np.asarray(plain_st)).all() and all_status[5] != 0
+    assert list(all_sizes) == [len(t) if i != 5 else 0 for i, t in enumerate(texts)]
+    assert totals == (sum(len(c) for c in streams), sum(len(t) for i, t in enumerate(texts) if i != 5), 1)

@@ -40,16 +40,26 @@ def _worker(rank, world, port, q):
     streams[4] = streams[4][:-3]  # one broken item must not disturb the others
 
     def local(sub, s, e):
-        res, st = [], []
+        res, sz, st = [], [], []
         for k, c in enumerate(sub):
             r, _, out = o.decompress(c, len(texts[s + k]), o.FMT_GZIP)
             res.append(out if r == 0 else None)
+            sz.append(len(out) if r == 0 else 0)
             st.append(r)
-        return res, np.array(st, dtype=np.int32)
+        return res, np.array(sz, dtype=np.int64), np.array(st, dtype=np.int32)
 
-    (s, e), res, all_status = run_sharded(streams, [len(c) for c in streams], local, dist)
+    (s, e), res, all_sizes, all_status, totals = run_sharded(streams, [len(c) for c in streams], local, dist)
     ok = all(res[k] == (texts[s + k] if s + k != 4 else None) for k in range(e - s))
-    q.put((rank, s, e, ok, all_status.tolist()))
+    # the payload gather: every rank's packed output lands on rank 0 in item order
+    import torch
+    from libdeflate_rsx_amd.sharding import gather_packed
+    packed = torch.from_numpy(np.frombuffer(b"".join(r for r in res if r is not None), dtype=np.uint8).copy())
+    whole = gather_packed(packed, dist, root=0)
+    if rank == 0:
+        ok = ok and whole.numpy().tobytes() == b"".join(t for i, t in enumerate(texts) if i != 4)
+    else:
+        ok = ok and whole is None
+    q.put((rank, s, e, ok, all_status.tolist(), all_sizes.tolist(), list(totals)))
     dist.destroy_process_group()
 
 
@@ -66,6 +76,9 @@ def test_two_ranks_cover_the_batch_and_agree():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, s0, e0, ok0, st0), (r1, s1, e1, ok1, st1) = out
+    (r0, s0, e0, ok0, st0, sz0, tot0), (r1, s1, e1, ok1, st1, sz1, tot1) = out
     assert (s0, e1) == (0, 9) and e0 == s1 and ok0 and ok1
     assert st0 == st1 and [x != 0 for x in st0] == [i == 4 for i in range(9)]
+    want_sizes = [20000 + 3000 * i if i != 4 else 0 for i in range(9)]
+    assert sz0 == sz1 == want_sizes
+    assert tot0 == tot1 and tot0[1] == sum(want_sizes) and tot0[2] == 1

@@ -3,7 +3,7 @@
 ROOT="$(pwd)"; tag="$1"; shift
 OUT="$ROOT/gpurun_out/kstats/$tag"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 "$@" > "$OUT/bench_line.json" || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-secondary --steps 3 --warmup 1 "$@" > "$OUT/bench_line.json" || exit 1
 f=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

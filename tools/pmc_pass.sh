@@ -9,5 +9,5 @@ mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
 timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT" -- \
-    python3 "$ROOT/bench.py" --op "$op" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null
+    python3 "$ROOT/bench.py" --op "$op" --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null
 echo "[pmc] $tag done"
