@@ -1025,6 +1025,7 @@ __device__ void decode_round_parallel(StreamLds &L, const StreamCtx &c, int64_t 
 template <class LS>
 __device__ void copy_round(LS &L, const StreamCtx &c)
 {
+    constexpr uint32_t kRing = sizeof(L.ring), kRingMask = kRing - 1;   // (this struct's ring, a power of two)
     const uint32_t nm = L.num_matches;
     const uint32_t round_start = L.round_start_lo;
     const uint32_t round_end = L.round_end_lo;
@@ -1152,26 +1153,27 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
         // bytes that have left the ring (read back from the output)
         {
-            uint8_t byte[kPer];
+            // sources that have left the ring are read back from the output: every such load of a lane is
+            // issued before the first one is waited for (one memory latency per step, not one per byte)
+            uint32_t sp[kPer];
+            uint8_t far_byte[kPer], byte[kPer];
+            bool far[kPer];
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                byte[k] = 0;
-                if (v[k] != kSelf) {
-                    // (32-bit positions) in front of the step, or a literal of the step
-                    const uint32_t sp = sub_start + v[k] - (v[k] >= kFront ? 0x10000u : kLanded);
-                    const bool far = round_end - sp > kRing;                   // has left the ring
-                    // two separate reads: written as one conditional expression the compiler
-                    // folds them into a single FLAT load whose address is either in LDS or in
-                    // global memory
-                    const uint8_t in_ring = L.ring[(sp + c.shift) & kRingMask];
-                    uint8_t far_byte = 0;
-                    if (far) far_byte = *((const __attribute__((address_space(1))) uint8_t *)c.out + sp);
-                    byte[k] = far ? far_byte : in_ring;
-                }
+                // (32-bit positions) in front of the step, or a literal of the step
+                sp[k] = sub_start + v[k] - (v[k] >= kFront ? 0x10000u : kLanded);
+                far[k] = v[k] != kSelf && round_end - sp[k] > kRing;
             }
 #pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                far_byte[k] = 0;
+                if (far[k]) far_byte[k] = *((const __attribute__((address_space(1))) uint8_t *)c.out + sp[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) byte[k] = L.ring[(sp[k] + c.shift) & kRingMask];   // (an LDS read, never a flat one)
+#pragma unroll
             for (int k = 0; k < kPer; k++)
-                if (v[k] != kSelf) L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = byte[k];
+                if (v[k] != kSelf) L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = far[k] ? far_byte[k] : byte[k];
         }
         WG_SYNC();
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tc; tc = t; }
@@ -1185,6 +1187,7 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
 template <class LS>
 __device__ void flush_range(LS &L, const StreamCtx &c, uint32_t from, uint32_t to)
 {
+    constexpr uint32_t kRingMask = sizeof(L.ring) - 1;
     if (to <= from) return;   // (uniform)
     const uint32_t g_from = from + c.shift, g_to = to + c.shift;  // = global address mod-16 phase
     const uint32_t u0 = g_from >> 4, u1 = (g_to + 15) >> 4;
@@ -1497,10 +1500,10 @@ constexpr uint32_t kLaneBytesStop = 8192; // a sub-sequence stops once it has pr
 static_assert(kLaneBytesStop + 258 <= kRoundOut, "one sub-sequence must fit a round of the expander");
 static_assert(kTokCap <= kMaxMatches, "one sub-sequence must fit the match queue");
 #ifndef RSX_DEC_SUB_BITS
-#define RSX_DEC_SUB_BITS 504
+#define RSX_DEC_SUB_BITS 448
 #endif
 #ifndef RSX_DEC_WARM_BITS
-#define RSX_DEC_WARM_BITS 504
+#define RSX_DEC_WARM_BITS 896
 #endif
 constexpr uint32_t kDecSubMax = RSX_DEC_SUB_BITS;      // longest sub-sequence (bits)
 constexpr uint32_t kDecSubMin = 32;
@@ -1708,7 +1711,10 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
     return kHdrRows + mx;
 }
 
-__global__ __launch_bounds__(kT, 5) void inflate_decode_kernel(
+#ifndef RSX_DEC_OCC
+#define RSX_DEC_OCC 6
+#endif
+__global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, int32_t *__restrict__ status, uint64_t *__restrict__ body_end, SplitLayout lay)
 {
@@ -1825,9 +1831,14 @@ __global__ __launch_bounds__(kT, 5) void inflate_decode_kernel(
 
 // LDS of the second kernel: the output ring, the copy phase's pointer table (named win: copy_round is
 // shared with inflate_kernel) and the match queue.
+#ifndef RSX_XRING
+#define RSX_XRING 16384
+#endif
+constexpr uint32_t kXRing = RSX_XRING, kXRingMask = kXRing - 1;   // the second kernel's ring
+static_assert((kXRing & kXRingMask) == 0 && kXRing >= kRing && kXRing <= 65536, "a power of two that holds a round");
 struct __align__(16) ExpandLds {
     uint32_t win[kWinWords + 4];
-    uint8_t ring[kRing];
+    uint8_t ring[kXRing];
     MatchQueue mq;
     uint32_t scan_carry[2 * (kT / 64) + 4];
     uint32_t stat_copy;
@@ -1841,7 +1852,15 @@ struct __align__(16) ExpandLds {
     uint8_t lane_steps[kT];  // its decoder steps
 };
 
-__global__ __launch_bounds__(kT, 5) void inflate_expand_kernel(
+#ifndef RSX_XOCC
+#define RSX_XOCC 5
+#endif
+#ifndef RSX_XGROUP
+#define RSX_XGROUP (16384 - 16)
+#endif
+constexpr uint32_t kXGroupOut = RSX_XGROUP;   // output bytes per group of the second kernel
+static_assert(kLaneBytesStop + 258 <= kXGroupOut && kXGroupOut <= kRoundOut, "one sub-sequence fits a group, a group the ring");
+__global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
     int32_t *__restrict__ status, SplitLayout lay)
@@ -1901,7 +1920,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_expand_kernel(
             const uint8_t *sp = c.body + src_byte;
             for (uint32_t done = 0; done < len;) {
                 const uint32_t piece = len - done < kRoundOut ? len - done : kRoundOut;
-                for (uint32_t k = tid; k < piece; k += kT) L.ring[(pos + k + c.shift) & kRingMask] = sp[done + k];
+                for (uint32_t k = tid; k < piece; k += kT) L.ring[(pos + k + c.shift) & kXRingMask] = sp[done + k];
                 WG_SYNC();
                 pos += piece;
                 done += piece;
@@ -1931,7 +1950,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_expand_kernel(
             }
             WG_SYNC();
             const uint32_t bb = L.base_bytes, bn = L.base_nm;
-            const bool fits = exb + bytes - bb <= kRoundOut && exn + nm - bn <= kMaxMatches;
+            const bool fits = exb + bytes - bb <= kXGroupOut && exn + nm - bn <= kMaxMatches;
             if ((uint32_t)tid > g0 && (uint32_t)tid < nlanes && !fits) atomicMin(&L.group_end, (uint32_t)tid);
             WG_SYNC();
             const uint32_t g1 = L.group_end;
@@ -1973,13 +1992,13 @@ __global__ __launch_bounds__(kT, 5) void inflate_expand_kernel(
                             const uint32_t len = (t & 0xFF) + 3, d1 = (t >> 8) & 0x7FFF;
                             err = err || d1 >= op;   // the distance reaches in front of the output
                             L.mq.dst[mi] = (uint16_t)(op - round_start);
-                            L.ring[(op + c.shift) & kRingMask] = (uint8_t)d1;
-                            L.ring[(op + c.shift + 1) & kRingMask] = (uint8_t)(d1 >> 8);
-                            L.ring[(op + c.shift + 2) & kRingMask] = (uint8_t)(len - 3);
+                            L.ring[(op + c.shift) & kXRingMask] = (uint8_t)d1;
+                            L.ring[(op + c.shift + 1) & kXRingMask] = (uint8_t)(d1 >> 8);
+                            L.ring[(op + c.shift + 2) & kXRingMask] = (uint8_t)(len - 3);
                             op += len;
                             mi++;
                         } else {
-                            L.ring[(op + c.shift) & kRingMask] = (uint8_t)t;
+                            L.ring[(op + c.shift) & kXRingMask] = (uint8_t)t;
                             op++;
                         }
                     }
