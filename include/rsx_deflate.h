@@ -51,6 +51,9 @@ extern "C" {
 #define RSX_SHORT_OUTPUT 2
 #define RSX_INSUFFICIENT_SPACE 3
 #define RSX_SHORT_INPUT 4
+/* not a DecompressResult: the engine stopped making progress on this item (an engine defect, never a
+ * property of the data); out_sizes[i] = 0.  A caller treats it like any other failed item. */
+#define RSX_INTERNAL_ERROR 100
 /* per-item compress status = CompressResult, src/compress/mod.rs:238-241:
  * 0 Success, 1 InsufficientSpace */
 #define RSX_COMPRESS_INSUFFICIENT_SPACE 1

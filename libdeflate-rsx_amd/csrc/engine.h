@@ -63,11 +63,18 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---- kernel launchers (each defined next to its kernels) ---------------------
 
 // Workgroup barrier.  The LDS writes of a wave must have landed before it signals the
-// barrier.  __syncthreads() alone leaves that to the compiler's wait-count insertion, which
-// (ROCm 7.2) drops the wait in front of a barrier at the head of a loop whose body ends in
-// LDS writes; other waves then read stale values when the LDS queue is deep.  The wait is
-// therefore written out.
+// barrier.  __syncthreads() alone leaves that to the compiler's wait-count insertion.  With
+// hipcc 7.2.0 -O3 the barrier at the head of the speculative decoder's pass loop (inflate.hip,
+// `for (pass ...) { WG_SYNC(); ... lane_exit[i] = ...; }`) comes out as a bare s_barrier on the
+// back edge although the loop body ends in ds_write instructions, and a faster wave then reads
+// the previous pass's lane_exit.  The wait is therefore written out; everywhere else it
+// duplicates one the compiler already emits.  tools/wg_sync_isa.sh compares both builds and
+// tools/barrier_waits.py lists every barrier reachable with an LDS access outstanding.
+#ifndef RSX_PLAIN_SYNC
 #define WG_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#else   // only for comparing the generated code
+#define WG_SYNC() __syncthreads()
+#endif
 
 // checksum.hip
 int checksum_tables_create(rsx_engine *e);

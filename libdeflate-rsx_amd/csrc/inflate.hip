@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
             seen_bitpos = bp;
             WG_SYNC();
             if (stalled > 4) {
-                if (tid == 0) L.status = RSX_BAD_DATA;
+                if (tid == 0) L.status = RSX_INTERNAL_ERROR;   // (not the data's fault: its own code)
                 WG_SYNC();
                 break;
             }

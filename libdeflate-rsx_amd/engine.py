@@ -7,6 +7,7 @@ import numpy as np
 
 FORMAT_DEFLATE, FORMAT_ZLIB, FORMAT_GZIP = 0, 1, 2
 SUCCESS, BAD_DATA, SHORT_OUTPUT, INSUFFICIENT_SPACE, SHORT_INPUT = range(5)
+INTERNAL_ERROR = 100   # the engine made no progress on an item (never a property of the data)
 CHECKSUM_CRC32, CHECKSUM_ADLER32 = 0, 1
 FLUSH_SYNC, FLUSH_FINISH = 1, 2   # FlushMode, src/compress/mod.rs:424-429
 

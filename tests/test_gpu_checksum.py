@@ -63,3 +63,28 @@ def test_chaining(rsx):
     d = corpus.random_bytes(200000, 9)
     assert rsx.crc32(rsx.crc32(0, d[:77777]), d[77777:]) == o.crc32(d)
     assert rsx.adler32(rsx.adler32(1, d[:77777]), d[77777:]) == o.adler32(d)
+
+
+def test_device_entry_point(rsx, eng):
+    # rsx_batch_checksum_device on device buffers: the caller's `max_item` only sizes the launch; values
+    # are right whether it is exact, generous or understated
+    import torch
+    dev = torch.device("cuda", 0)
+    items = [corpus.text(100000, 1), b"", corpus.random_bytes(32768, 2), corpus.mixed(70001, 3), b"x"]
+    n = len(items)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[0] = 77   # (the batch does not start at the buffer's first byte)
+    off[1:] = 77 + np.cumsum([len(it) for it in items])
+    h = np.concatenate([np.zeros(77, dtype=np.uint8), np.frombuffer(b"".join(items), dtype=np.uint8)])
+    d_in = torch.from_numpy(h.copy()).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_val = torch.zeros(n, dtype=torch.int32, device=dev)
+    e2 = rsx.Engine(0, torch.cuda.current_stream(dev).cuda_stream)
+    for kind, ref, init in ((rsx.CHECKSUM_CRC32, zlib.crc32, 0), (rsx.CHECKSUM_ADLER32, zlib.adler32, 1)):
+        for max_item in (100000, 1 << 20, 4096):
+            d_val.zero_()
+            e2.batch_checksum_device(kind, init, d_in.data_ptr(), d_off.data_ptr(), n, int(off[-1] - off[0]), max_item,
+                                     d_val.data_ptr())
+            torch.cuda.synchronize(dev)
+            got = d_val.cpu().numpy().view(np.uint32)
+            assert [int(x) for x in got] == [ref(it) for it in items], (kind, max_item)

@@ -197,3 +197,103 @@ def test_run_sharded_with_the_engine_matches_the_unsharded_call(eng, rsx):
     assert (np.asarray(all_status) == np.asarray(plain_st)).all() and all_status[5] != 0
     assert list(all_sizes) == [len(t) if i != 5 else 0 for i, t in enumerate(texts)]
     assert totals == (sum(len(c) for c in streams), sum(len(t) for i, t in enumerate(texts) if i != 5), 1)
+
+
+def test_understated_longest_item_keeps_trailers_right(eng, rsx):
+    # zlib and gzip carry a checksum of the input in their trailer: an understated `max_item` may cost
+    # compression, never a wrong Adler-32 / CRC-32 (zlib checks both when it inflates the output)
+    import torch
+    dev = torch.device("cuda", 0)
+    datas = [corpus.text(4096, 710), corpus.text(200000, 711), corpus.mixed(3000, 712), corpus.text(70000, 713),
+             corpus.text(40000, 714)]
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.uint64)
+    in_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=in_off[1:])
+    e2 = rsx.Engine(0, torch.cuda.current_stream(dev).cuda_stream)
+    d_in = torch.from_numpy(np.frombuffer(b"".join(datas), dtype=np.uint8).copy()).to(dev)
+    d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
+    for fmt, wbits in ((rsx.FORMAT_ZLIB, 15), (rsx.FORMAT_GZIP, 31)):
+        bounds = np.array([rsx.compress_bound(fmt, len(d)) for d in datas], dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(bounds, out=out_off[1:])
+        d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
+        d_out = torch.zeros(int(out_off[-1]) + 4096, dtype=torch.uint8, device=dev)
+        d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        e2.batch_compress_device(fmt, 6, d_in.data_ptr(), d_in_off.data_ptr(), n, int(in_off[-1]),
+                                 4096, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                 d_status.data_ptr())   # max_item claims 4096
+        torch.cuda.synchronize(dev)
+        st, sz, out = d_status.cpu().numpy(), d_sizes.cpu().numpy(), d_out.cpu().numpy()
+        assert (out[int(out_off[-1]):] == 0).all()
+        for i, d in enumerate(datas):
+            assert st[i] in (0, 1)
+            if st[i] == 0:
+                c = out[int(out_off[i]):int(out_off[i]) + int(sz[i])].tobytes()
+                assert zlib.decompress(c, wbits) == d, (fmt, i)   # (raises on a wrong trailer)
+        assert st[0] == 0 and st[2] == 0
+
+
+def test_understated_max_out_still_decodes(eng, rsx):
+    # rsx_batch_decompress_device with a `max_out` smaller than the largest slot: the trailer check must
+    # still see the right checksum of every item
+    import torch
+    dev = torch.device("cuda", 0)
+    texts = [corpus.text(150000, 720), corpus.text(5000, 721), corpus.text(90000, 722)]
+    for fmt, ofmt in ((rsx.FORMAT_GZIP, 2), (rsx.FORMAT_ZLIB, 1)):
+        streams = [o.compress(t, 6, ofmt) for t in texts]
+        n = len(texts)
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in streams], out=in_off[1:])
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(t) for t in texts], out=out_off[1:])
+        d_in = torch.from_numpy(np.frombuffer(b"".join(streams), dtype=np.uint8).copy()).to(dev)
+        d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
+        d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
+        d_out = torch.zeros(int(out_off[-1]), dtype=torch.uint8, device=dev)
+        d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        e2 = rsx.Engine(0, torch.cuda.current_stream(dev).cuda_stream)
+        e2.batch_decompress_device(fmt, d_in.data_ptr(), d_in_off.data_ptr(), n, int(in_off[-1]), int(out_off[-1]),
+                                   4096, d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(),
+                                   d_status.data_ptr())   # max_out claims 4096
+        torch.cuda.synchronize(dev)
+        assert d_status.cpu().numpy().tolist() == [0, 0, 0]
+        assert d_out.cpu().numpy().tobytes() == b"".join(texts)
+
+
+def test_device_batch_with_an_offset_base_and_unaligned_slots(eng, rsx):
+    # in_off[0] != 0 (the batch is a slice of a larger buffer) and output slots at odd addresses: the bytes
+    # of the batch are in[in_off[0] .. in_off[n]), and the last stream must read all of its own
+    import torch
+    dev = torch.device("cuda", 0)
+    texts = [corpus.text(70001, 730), corpus.mixed(33333, 731), corpus.text(120007, 732)]
+    for fmt, ofmt in ((rsx.FORMAT_DEFLATE, 0), (rsx.FORMAT_GZIP, 2)):
+        streams = [o.compress(t, 6, ofmt) for t in texts]
+        n = len(texts)
+        lead = 12345   # bytes in front of the batch that do not belong to it
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        in_off[0] = lead
+        in_off[1:] = lead + np.cumsum([len(s) for s in streams])
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        out_off[0] = 3
+        out_off[1:] = 3 + np.cumsum([len(t) for t in texts])
+        h_in = np.concatenate([np.full(lead, 0xEE, dtype=np.uint8), np.frombuffer(b"".join(streams), dtype=np.uint8)])
+        d_in = torch.from_numpy(h_in.copy()).to(dev)
+        d_in_off = torch.from_numpy(in_off.view(np.int64)).to(dev)
+        d_out_off = torch.from_numpy(out_off.view(np.int64)).to(dev)
+        d_out = torch.full((int(out_off[-1]) + 5,), 0x77, dtype=torch.uint8, device=dev)
+        d_sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        e2 = rsx.Engine(0, torch.cuda.current_stream(dev).cuda_stream)
+        for call in (e2.batch_decompress_device, e2.batch_decompress_device_noalloc):
+            d_out.fill_(0x77)
+            call(fmt, d_in.data_ptr(), d_in_off.data_ptr(), n, int(in_off[-1] - in_off[0]),
+                 int(out_off[-1] - out_off[0]), max(len(t) for t in texts), d_out.data_ptr(), d_out_off.data_ptr(),
+                 d_sizes.data_ptr(), d_status.data_ptr())
+            torch.cuda.synchronize(dev)
+            assert d_status.cpu().numpy().tolist() == [0, 0, 0]
+            out = d_out.cpu().numpy()
+            assert out[3:int(out_off[-1])].tobytes() == b"".join(texts)
+            assert (out[:3] == 0x77).all() and (out[int(out_off[-1]):] == 0x77).all()
