@@ -427,6 +427,68 @@ def bench_strong(args, ctx):
     }
 
 
+def bench_large(args, ctx):
+    """One large buffer (src/api.rs:22-57: the reference cuts inputs above 256 KiB into 256 KiB chunks, compresses
+    them in parallel and joins them with sync-flush markers, src/compress/mod.rs:699-772): a batch of ONE item of
+    --large-mib MiB of text, gzip level --level.  The chunks are the unit of parallelism: 64 MiB = 256 chunks = one
+    workgroup per CU.  The output is inflated on the GPU (one stream, so one workgroup: reported, not the metric)
+    and by the oracle, and compared with the input."""
+    import corpus
+    import oracle_lib as orc
+    rsx, torch = ctx.rsx, ctx.torch
+    fmt, level = rsx.FORMAT_GZIP, args.level
+    size = args.large_mib << 20
+    piece = min(size, 8 << 20)
+    data = b"".join(corpus.text(piece, 31000 + 1000 * ctx.rank + k) for k in range((size + piece - 1) // piece))[:size]
+    d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(ctx.dev)
+    bound = int(rsx.compress_bound(fmt, size))
+    d_in_off = torch.tensor([0, size], dtype=torch.int64, device=ctx.dev)
+    d_out_off = torch.tensor([0, bound], dtype=torch.int64, device=ctx.dev)
+    d_out = torch.zeros(bound, dtype=torch.uint8, device=ctx.dev)
+    d_sizes = torch.zeros(1, dtype=torch.int64, device=ctx.dev)
+    d_status = torch.full((1,), -7, dtype=torch.int32, device=ctx.dev)
+
+    def step():
+        ctx.eng.batch_compress_device(fmt, level, d_in.data_ptr(), d_in_off.data_ptr(), 1, size, size,
+                                      d_out.data_ptr(), d_out_off.data_ptr(), d_sizes.data_ptr(), d_status.data_ptr())
+
+    dt, k_ms = timed_steps(ctx, step, args.steps, args.warmup)
+    csize = int(d_sizes.item())
+    if int(d_status.item()) != 0:
+        raise SystemExit("bench.py: compressing the large buffer failed with status %d" % int(d_status.item()))
+    # inflate the stream on the GPU (a single stream: one workgroup) and with the oracle
+    d_back = torch.empty(size, dtype=torch.uint8, device=ctx.dev)
+    b_off = torch.tensor([0, size], dtype=torch.int64, device=ctx.dev)
+    c_off = torch.tensor([0, csize], dtype=torch.int64, device=ctx.dev)
+    b_sizes = torch.zeros(1, dtype=torch.int64, device=ctx.dev)
+    b_status = torch.full((1,), -7, dtype=torch.int32, device=ctx.dev)
+    ctx.eng.batch_decompress_device(fmt, d_out.data_ptr(), c_off.data_ptr(), 1, csize, size, size,
+                                    d_back.data_ptr(), b_off.data_ptr(), b_sizes.data_ptr(), b_status.data_ptr())
+    torch.cuda.synchronize(ctx.dev)
+    inflate_ms = ctx.eng.last_kernel_ms()
+    ok = int(b_status.item()) == 0 and int(b_sizes.item()) == size and bool((d_back == d_in).all())
+    comp = d_out[:csize].cpu().numpy().tobytes()
+    r, used, back = orc.decompress(comp, size, orc.FMT_GZIP)
+    ok = ok and r == 0 and used == csize and back == data
+    if not ok:
+        raise SystemExit("bench.py: the large buffer did not survive the round trip")
+    job_bytes = ctx.sum_over_ranks(size + csize)
+    achieved = (size + csize) / (k_ms * 1e-3) / 1e9
+    return {
+        "value": job_bytes * args.steps / dt / 2**30, "unit": "GiB/s", "ms_per_step": dt / args.steps * 1e3,
+        "scaling": "weak",
+        "config": {"workload": "one %d MiB text buffer per GPU, gzip compress level %d, batch of 1 (chunk-parallel: "
+                               "%d x 256 KiB chunks joined by sync-flush markers)" % (args.large_mib, level, size >> 18),
+                   "op": "compress", "format": "gzip", "level": level, "buf_bytes": size,
+                   "compressed_ratio": size / csize, "verified": ok,
+                   "single_stream_inflate_ms": inflate_ms,
+                   "single_stream_inflate_gibps": (size + csize) / (inflate_ms * 1e-3) / 2**30},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "deflate_chunks_kernel",
+                     "kernel_ms": k_ms, "algorithmic_bytes": size + csize},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,9 +503,10 @@ def main():
     ap.add_argument("--level", type=int, default=6, help="compress only")
     ap.add_argument("--corpus", choices=["mixed", "json", "text"], default="mixed",
                     help="compress only: mixed = zlib (headline), json/text = raw deflate")
-    ap.add_argument("--op", choices=["decompress", "compress"], default="decompress",
+    ap.add_argument("--op", choices=["decompress", "compress", "large"], default="decompress",
                     help="decompress = gzip level-6 text (headline) with the compress leg attached; "
-                         "compress = zlib level-6 mixed alone")
+                         "compress = zlib level-6 mixed alone; large = one --large-mib MiB buffer, batch of 1")
+    ap.add_argument("--large-mib", type=int, default=64, help="--op large: size of the single buffer")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     argv = sys.argv[1:]
     args = ap.parse_args(argv)
@@ -460,6 +523,8 @@ def main():
         res = bench_strong(args, ctx)
     elif args.op == "compress":
         res = bench_compress(args, ctx)
+    elif args.op == "large":
+        res = bench_large(args, ctx)
     else:
         res = bench_decompress(args, ctx)
         if not args.no_secondary:

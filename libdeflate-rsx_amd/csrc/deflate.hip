@@ -47,10 +47,22 @@ namespace {
 
 constexpr int kCT = 1024;                       // threads per chunk
 constexpr uint32_t kChunk = 256 * 1024;         // src/compress/mod.rs:699-700
-constexpr int kHashBits = 13;                   // 32-bit LDS exchange words: 2^13 heads = 32 KiB
-                                                // (the reference hashes to 15 bits, matchfinder.rs:784)
-constexpr int kHash3Bits = 11;
-constexpr uint32_t kMaxDist3 = 4096;           // farthest match of length 3 worth its offset bits
+// Match finder table (LDS): 2^kRowBits rows of kWays entries.  A position goes to the row its 4
+// bytes hash to, into the slot its own number hashes to; an entry is (position + 1) << kTagBits |
+// tag with kTagBits more bits of the hash, and the newest position wins a slot (atomic max), so
+// the table does not depend on the order the lanes arrive in.  (The reference keeps hash chains,
+// matchfinder.rs:754-891: a chain is a serial walk of dependent loads, a row is read at once and
+// its tags drop nearly every candidate that is only a hash collision.)
+constexpr int kRowBits = 11;
+constexpr uint32_t kRows = 1u << kRowBits;
+constexpr uint32_t kWays = 12;
+constexpr uint32_t kTagBits = 13;
+constexpr uint32_t kTagMask = (1u << kTagBits) - 1;
+static_assert(256 * 1024 + 1 < (1u << (32 - kTagBits)), "position + 1 fits above the tag");
+// Levels 7-12 keep the reference's hash chains (every older position with the same hash can be
+// reached, which is what deep searches pay for); the tables share the rows' LDS.
+constexpr int kHashBits = 13;                   // 2^13 heads (the reference hashes to 15 bits, matchfinder.rs:784)
+constexpr uint32_t kNearDist = 8;               // distances 1..kNearDist are checked from registers
 constexpr uint32_t kWindow = 32768;
 constexpr uint32_t kBlockSoft = 65535 - kCT - 300;  // close the block once it holds this many bytes
 constexpr uint32_t kTokCap = 66 * 1024;         // tokens per block (<= bytes per block)
@@ -82,18 +94,23 @@ __constant__ uint8_t k_precode_perm[19] = {16, 17, 18, 0, 8,  7, 9,  6, 10, 5,
 struct LevelParams {
     uint32_t max_depth, nice_len, lazy;
     uint32_t optimal;   // levels 10-12: cost-based parse over all recorded matches
+    uint32_t chains;    // levels 7-12: hash chains instead of the row table
 };
 
 // src/compress/mod.rs:543-602 and :624-630
 __host__ inline LevelParams level_params(int level)
 {
-    static const uint32_t depth[13] = {0, 2, 6, 12, 16, 16, 35, 100, 300, 600, 35, 100, 300};
+    // levels 1-6: candidates compared per position (the row's tags drop the hash collisions a
+    // chain of the reference's depth 2, 6, 12, 16, 16, 35 spends most of its steps on);
+    // levels 7-12: chain steps, the reference's numbers
+    static const uint32_t depth[13] = {0, 2, 4, 4, 6, 6, 8, 100, 300, 600, 35, 100, 300};
     static const uint32_t nice[13] = {0, 32, 10, 14, 30, 30, 65, 130, 258, 258, 75, 150, 258};
     LevelParams p;
     p.max_depth = depth[level];
     p.nice_len = nice[level];
     p.lazy = level >= 5 ? 1 : 0;
     p.optimal = level >= 10 ? 1 : 0;
+    p.chains = level >= 7 ? 1 : 0;
     return p;
 }
 
@@ -111,9 +128,13 @@ __device__ inline uint32_t offset_slot(uint32_t dist)
 
 struct __align__(16) ChunkLds {
     uint8_t inbuf[kInBuf + 32];      // input bytes [w0 - phase, w0 - phase + kInBuf) of the chunk
-    uint32_t head[1 << kHashBits];   // newest position + 1 per 4-byte hash, 0 = empty
-    uint32_t head3[1 << kHash3Bits]; // newest position + 1 per 3-byte hash
-    uint16_t prev[kWindow];          // distance to the next older position with the same hash
+    union {
+        uint32_t rows[kRows * kWays];    // (position + 1) << kTagBits | tag, 0 = empty
+        struct {
+            uint32_t head[1 << kHashBits];   // newest position + 1 per 4-byte hash, 0 = empty
+            uint16_t prev[32768];            // distance to the next older position with the same hash
+        } chain;
+    };
     uint16_t m_len[kCT + 2];         // best match per parse slot: slot 0 = last position of the
     uint16_t m_off[kCT + 2];         //   previous batch, slots 1..kCT = this batch
     uint16_t jump[2][kCT + 2];       // pointer-jumping tables (slot -> slot, kCT+1 = past the end)
@@ -588,17 +609,19 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
     WG_SYNC();
 }
 
-__device__ inline uint32_t load_le32(const uint8_t *p)
+// Bytes at any byte offset of an LDS buffer, read as aligned dwords and shifted into place: an LDS
+// load whose address is not a multiple of its size is handled one lane at a time (64 cycles per
+// wave instruction against 2-8 for an aligned one, tools/micro/lds_rate.hip).
+// `buf` is 4-byte aligned; up to 3 bytes past the last requested byte are read as well.
+template <int kWords>
+__device__ inline void lds_bytes(const uint8_t *buf, uint32_t at, uint32_t (&w)[kWords])
 {
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
-__device__ inline uint64_t load_le64(const uint8_t *p)
-{
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(buf) + (at >> 2);
+    uint32_t d[kWords + 1];
+#pragma unroll
+    for (int k = 0; k <= kWords; k++) d[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < kWords; k++) w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], at);
 }
 
 // Index of the first non-zero byte of the 20 bytes x0..x4 (little endian), 20 if there is none.
@@ -623,17 +646,22 @@ __device__ inline uint32_t first_diff_byte(uint32_t x0, uint32_t x1, uint32_t x2
     return byte < 20 ? byte : 20;
 }
 
-// length of the common prefix of a and b, at most max_len (a < b, both inside the chunk)
-__device__ inline uint32_t match_length(const uint8_t *a, const uint8_t *b, uint32_t max_len)
+// length of the common prefix of the LDS bytes at offsets a and b of buf, at most max_len
+__device__ inline uint32_t match_length(const uint8_t *buf, uint32_t a, uint32_t b, uint32_t max_len)
 {
     uint32_t n = 0;
-    while (n + 8 <= max_len) {
-        uint64_t x = load_le64(a + n) ^ load_le64(b + n);
-        if (x) return n + (uint32_t)(__ffsll((long long)x) - 1) / 8;
+    while (n < max_len) {
+        uint32_t x[2], y[2];
+        lds_bytes<2>(buf, a + n, x);
+        lds_bytes<2>(buf, b + n, y);
+        const uint32_t z0 = x[0] ^ y[0], z1 = x[1] ^ y[1];
+        if (z0 | z1) {
+            n += z0 ? (uint32_t)(__ffs((int)z0) - 1) / 8 : 4 + (uint32_t)(__ffs((int)z1) - 1) / 8;
+            break;
+        }
         n += 8;
     }
-    while (n < max_len && a[n] == b[n]) n++;
-    return n;
+    return n < max_len ? n : max_len;
 }
 
 // ---- levels 10-12: cost-based parse (src/compress/mod.rs:1586-1773) --------------------
@@ -768,7 +796,7 @@ __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, u
 // mp / blkcost: per-workgroup buffers of the cost-based parse (levels 10-12 only).
 // kOptimal: levels 10-12 (cost-based parse); a compile-time switch keeps the recording and
 // replay code out of the kernel of the other levels
-template <bool kOptimal>
+template <bool kOptimal, bool kChains>
 __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, bool last_chunk,
                                    LevelParams lp, uint32_t *tok, uint32_t *out_words, uint32_t *mp,
                                    uint8_t *blkcost)
@@ -779,8 +807,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         uint4 *z = reinterpret_cast<uint4 *>(out_words);
         const uint32_t units = (n + kScratchPad) / 16;
         for (uint32_t u = tid; u < units; u += kCT) z[u] = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = tid; i < (1u << kHashBits); i += kCT) L.head[i] = 0;
-        for (uint32_t i = tid; i < (1u << kHash3Bits); i += kCT) L.head3[i] = 0;
+        for (uint32_t i = tid; i < (kChains ? (1u << kHashBits) : kRows * kWays) / 4; i += kCT)
+            reinterpret_cast<uint4 *>(L.rows)[i] = make_uint4(0, 0, 0, 0);   // (the chain heads lie in front)
         for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
         if (tid < 32) L.off_freq[tid] = 0;
         for (int i = tid; i < 260; i += kCT) {
@@ -854,8 +882,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         // pieces of all blocks, dealt round-robin to the waves; the hash tables are idle now
         {
             const uint32_t wave = tid >> 6;
-            uint32_t *ws = reinterpret_cast<uint32_t *>(L.prev) + wave * 1024;
-            static_assert(sizeof(L.prev) >= (kCT / 64) * 4096, "per-wave scratch of the parse");
+            uint32_t *ws = L.rows + wave * 1024;   // (the match finder's tables are idle by now)
+            static_assert(sizeof(L.rows) >= (kCT / 64) * 4096, "per-wave scratch of the parse");
             uint32_t k = 0, s0 = 0;
             for (uint32_t piece = 0; piece < L.ncut; piece++) {
                 const uint32_t c = L.cut[piece], e0 = c & 0x7FFFFFFFu;
@@ -910,80 +938,186 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         const uint32_t p = b0 + tid;
         uint32_t best_len = 0, best_off = 0;
         const bool can = !replay && p + 3 <= n;   // matchfinder.rs:765-767
-        // chains link positions by a hash of 4 bytes; a second table remembers the newest
-        // position per 3-byte hash for the matches of length 3 the chains cannot see
-        const bool can4 = p + 4 <= n;
-        uint32_t h = 0, h3 = 0, src4 = 0;
+        const bool can4 = can && p + 4 <= n;
+        uint32_t src4 = 0, row = 0, tag = 0, near = 0, w0r = 0, w1r = 0;
+        uint64_t src_a = 0, src_b = 0;
+        bool repeats = false;
         if (can) {
-            src4 = load_le32(inp(p));   // bytes past the chunk end are never compared
-            h = (src4 * 0x1E35A7BDu) >> (32 - kHashBits);   // multiplier of matchfinder.rs:784
-            h3 = ((src4 << 8) * 0x1E35A7BDu) >> (32 - kHash3Bits);
-        }
-        // push on the chains one wave after the other, so that within a chain newer
-        // positions always sit in front of older ones (matchfinder.rs:788-805).  Heads hold
-        // position + 1, links the distance to the next older position (0 ends the chain).
-        uint32_t link = 0, older3 = 0;
-        for (int w = 0; w < kCT / 64; w++) {
-            if ((tid >> 6) == w && can) {
-                if (can4) {
-                    const uint32_t o = atomicExch(&L.head[h], p + 1), dlt = p + 1 - o;
-                    link = (o != 0 && dlt < 65536) ? dlt : 0;
-                }
-                L.prev[p & (kWindow - 1)] = (uint16_t)link;
-                older3 = atomicExch(&L.head3[h3], p + 1);
+            {
+                uint32_t w[5];
+                lds_bytes<5>(L.inbuf, p + phase - w0, w);   // bytes past the chunk end are never compared
+                src4 = w[0];
+                src_a = w[1] | ((uint64_t)w[2] << 32);
+                src_b = w[3] | ((uint64_t)w[4] << 32);
             }
-            WG_SYNC();
+            const uint32_t h = src4 * 0x1E35A7BDu;   // multiplier of matchfinder.rs:784
+            row = h >> (32 - kRowBits);
+            tag = (h >> (32 - kRowBits - kTagBits)) & kTagMask;
+            // distances 1..8: the bytes there are in registers with the 8 bytes in front of p
+            const uint32_t back = p < kNearDist ? p : kNearDist;
+            uint64_t before = 0;
+            if (back) {
+                uint32_t w[2];
+                lds_bytes<2>(L.inbuf, p - back + phase - w0, w);
+                before = (w[0] | ((uint64_t)w[1] << 32)) << (8 * (kNearDist - back));   // byte 7 = position p - 1
+            }
+            w0r = (uint32_t)before;
+            w1r = (uint32_t)(before >> 32);
+#pragma unroll
+            for (uint32_t d = 1; d <= kNearDist; d++) {
+                const uint32_t o = kNearDist - d;   // byte offset of position p - d in (before, src4)
+                const uint32_t c4 = o == 0 ? w0r : o < 4 ? __builtin_amdgcn_alignbyte(w1r, w0r, o)
+                                  : o == 4 ? w1r : __builtin_amdgcn_alignbyte(src4, w1r, o - 4);
+                const uint32_t x = c4 ^ src4;
+                if ((x & 0xFFFFFF) == 0 && d <= back) near |= 1u << d;
+                repeats = repeats || (x == 0 && d <= back);
+            }
         }
+        uint32_t link = 0;
+        if (kChains) {
+            // push on the chains one wave after the other, so that within a chain newer
+            // positions always sit in front of older ones (matchfinder.rs:788-805).  Heads hold
+            // position + 1, links the distance to the next older position (0 ends the chain).
+            const uint32_t h = (src4 * 0x1E35A7BDu) >> (32 - kHashBits);
+            for (int w = 0; w < kCT / 64; w++) {
+                if ((tid >> 6) == w && can) {
+                    if (can4) {
+                        const uint32_t o = atomicExch(&L.chain.head[h], p + 1), dlt = p + 1 - o;
+                        link = (o != 0 && dlt < 65536) ? dlt : 0;
+                    }
+                    L.chain.prev[p & 32767] = (uint16_t)link;
+                }
+                if (w + 1 < kCT / 64) WG_SYNC();
+            }
+        } else if (can4 && !repeats) {
+            // Push the position on its row.  A position whose 4 bytes repeat at a distance of
+            // 1..8 stays out (runs and short periods would flood one row, and the near check
+            // finds them).
+            const uint32_t slot = (((p * 0x9E3779B1u) >> 16) * kWays) >> 16;
+            atomicMax(&L.rows[row * kWays + slot], ((p + 1) << kTagBits) | tag);
+        }
+        WG_SYNC();
         DT_MARK(1);
         if (can && lp.max_depth) {
-            // Walk the chain (matchfinder.rs:808-870).  Per candidate one round of LDS
-            // reads (the link and 20 bytes of the candidate) decides lengths up to 20
-            // against the position's own first 20 bytes held in registers; only longer
-            // matches go through the extension loop.
+            // Candidates (matchfinder.rs:808-870 walks a chain here): first the near distances that
+            // passed the three-byte test, then the row's entries with this position's tag, newest
+            // first, two per round so that their loads overlap.  A candidate costs one round of
+            // LDS reads (20 bytes) compared with the position's own first 20 bytes in registers;
+            // only longer matches go through the extension loop.
             const uint32_t max_len = n - p < 258 ? n - p : 258;
             const uint32_t stop_len = lp.nice_len < max_len ? lp.nice_len : max_len;
             const uint32_t max_dist = p < 32768 ? p : 32768;   // matchfinder.rs:818
-            const uint8_t *src = inp(p);
-            const uint64_t src_a = load_le64(src + 4), src_b = load_le64(src + 12);
-            uint32_t dist = 0, npairs = 0;
+            const uint32_t src_at = p + phase - w0;   // offset of position p in the LDS input window
+            uint32_t npairs = 0;
             uint32_t *mpp = mp + (size_t)p * kPairs;
-            // one exit test per candidate; everything else is selects
-            uint32_t depth = 0;
-            bool go = link != 0 && link <= max_dist;
-            while (go) {
-                dist += link;
-                const uint32_t cand = p - dist;
-                const uint8_t *m = inp(cand);
-                link = L.prev[cand & (kWindow - 1)];
-                const uint32_t x4 = load_le32(m) ^ src4;
-                const uint64_t xa = load_le64(m + 4) ^ src_a, xb = load_le64(m + 12) ^ src_b;
-                // first differing bit among the 160: per dword "find first one" (all ones when the
-                // dword is equal) plus the dword's bit offset with a saturating add, then the minimum
-                uint32_t l = first_diff_byte(x4, (uint32_t)xa, (uint32_t)(xa >> 32), (uint32_t)xb, (uint32_t)(xb >> 32));
-                l = l < 3 ? 0u : l;   // (matchfinder.rs:835-853: nothing shorter than three bytes counts)
-                if (l == 20 && max_len > 20) l = 20 + match_length(m + 20, src + 20, max_len - 20);
+            const uint32_t S[5] = {src4, (uint32_t)src_a, (uint32_t)(src_a >> 32), (uint32_t)src_b, (uint32_t)(src_b >> 32)};
+            // length of the match at `dist` given its first 20 bytes
+            auto finish_length = [&](const uint32_t (&w)[5], uint32_t dist) -> uint32_t {
+                uint32_t l = first_diff_byte(w[0] ^ S[0], w[1] ^ S[1], w[2] ^ S[2], w[3] ^ S[3], w[4] ^ S[4]);
+                if (l == 20 && max_len > 20)
+                    l = 20 + match_length(L.inbuf, src_at - dist + 20, src_at + 20, max_len - 20);
                 l = l < max_len ? l : max_len;         // bytes past the chunk end do not count
-                const bool better = l > best_len;
-                best_len = better ? l : best_len;
-                best_off = better ? dist : best_off;
-                if (analysis && better) {
-                    // matches of increasing length, nearest first; the last slot keeps the longest
+                return l < 3 ? 0u : l;   // (matchfinder.rs:835-853: nothing shorter than three bytes counts)
+            };
+            auto consider = [&](uint32_t l, uint32_t dist) {
+                const bool better = l > best_len;   // candidates come nearest first
+                if (analysis && l > best_len) {
+                    // matches of increasing length; the last slot keeps the longest
                     const uint32_t slot = npairs < kPairs ? npairs : kPairs - 1;
                     mpp[slot] = l | ((dist - 1) << 9);
                     npairs = slot + 1;
                 }
-                depth++;
-                // matchfinder.rs:825, :851: stop at a nice match, at the end of the chain, of the
-                // window, of the search budget
-                go = l < stop_len && link != 0 && dist + link <= max_dist && depth < lp.max_depth;
+                best_len = better ? l : best_len;
+                best_off = better ? dist : best_off;
+            };
+            uint32_t it_near = 0, it_row = 0;
+            unsigned long long tn0 = RSX_DEV_TIMERS ? clock64() : 0;
+            // near distances: the candidate's first 20 bytes are the 8 bytes in front of p followed
+            // by p's own, all in registers
+            if (near) {
+                const uint32_t C[7] = {w0r, w1r, S[0], S[1], S[2], S[3], S[4]};
+#pragma unroll
+                for (uint32_t d = 1; d <= kNearDist; d++) {
+                    if ((near >> d) & 1) {
+                        const uint32_t o = kNearDist - d, i = o >> 2, sh = o & 3;
+                        uint32_t w[5];
+#pragma unroll
+                        for (uint32_t k = 0; k < 5; k++)
+                            w[k] = sh ? __builtin_amdgcn_alignbyte(C[i + k + 1], C[i + k], sh) : C[i + k];
+                        consider(finish_length(w, d), d);
+                    }
+                }
             }
-            if (best_len < 3 && older3 != 0) {
-                // length 3 only pays at short distances
-                const uint32_t d = p + 1 - older3;
-                if (d - 1 < kMaxDist3 && d <= p && ((load_le32(inp(p - d)) ^ src4) & 0xFFFFFF) == 0) {
-                    best_len = 3;
-                    best_off = d;
-                    if (analysis) mpp[npairs++] = 3 | ((d - 1) << 9);
+            unsigned long long tn1 = RSX_DEV_TIMERS ? clock64() : 0;
+            if (kChains) {
+                // Walk the chain (matchfinder.rs:808-870), nearest first.  A candidate that differs
+                // from p at offset best_len cannot be longer than the best so far: one byte decides.
+                uint32_t dist = 0, depth = 0;
+                uint32_t next_byte = best_len ? L.inbuf[src_at + best_len] : 0;
+                bool go = link != 0 && link <= max_dist && best_len < stop_len;
+                while (go) {
+                    dist += link;
+                    link = L.chain.prev[(p - dist) & 32767];
+                    if (!best_len || L.inbuf[src_at - dist + best_len] == next_byte) {
+                        uint32_t w[5];
+                        lds_bytes<5>(L.inbuf, src_at - dist, w);
+                        const uint32_t before_len = best_len;
+                        consider(finish_length(w, dist), dist);
+                        if (best_len != before_len && best_len < max_len) next_byte = L.inbuf[src_at + best_len];
+                    }
+                    depth++;
+                    it_row++;
+                    // matchfinder.rs:825, :851: stop at a nice match, at the end of the chain, of the
+                    // window, of the search budget
+                    go = best_len < stop_len && link != 0 && dist + link <= max_dist && depth < lp.max_depth;
+                }
+            } else if (can4 && best_len < stop_len) {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(&L.rows[row * kWays]);
+                const uint4 ra = rp[0], rb = rp[1], rc = rp[2];
+                const uint32_t e[kWays] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z, rc.w};
+                static_assert(kWays == 12, "three 16-byte reads per row");
+                // candidates: entries with this position's tag that lie in front of it inside the
+                // window (another tag, an empty entry, this or a later position of the batch fall
+                // out), taken nearest first: key = distance << 4 | slot, ~0 = none
+                uint32_t key[kWays];
+#pragma unroll
+                for (uint32_t k = 0; k < kWays; k++) {
+                    const uint32_t d = p + 1 - (e[k] >> kTagBits);
+                    const bool ok = ((e[k] ^ tag) & kTagMask) == 0 && d - 1 < max_dist;
+                    key[k] = ok ? (d << 4) | k : ~0u;
+                }
+                uint32_t depth = 0;
+                // the byte a candidate must match to be longer than the best so far
+                uint32_t next_byte = best_len ? L.inbuf[src_at + best_len] : 0;
+                while (depth < lp.max_depth && best_len < stop_len) {
+                    uint32_t v = key[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < kWays; k++) v = key[k] < v ? key[k] : v;
+                    if (v == ~0u) break;
+#pragma unroll
+                    for (uint32_t k = 0; k < kWays; k++) key[k] = key[k] == v ? ~0u : key[k];
+                    const uint32_t d0 = v >> 4;
+                    depth++;
+                    it_row++;
+                    if (best_len && L.inbuf[src_at - d0 + best_len] != next_byte) continue;
+                    uint32_t w[5];
+                    lds_bytes<5>(L.inbuf, src_at - d0, w);
+                    const uint32_t before_len = best_len;
+                    consider(finish_length(w, d0), d0);
+                    if (best_len != before_len && best_len < max_len) next_byte = L.inbuf[src_at + best_len];
+                }
+            }
+            if (RSX_DEV_TIMERS) {
+                unsigned long long tn2 = clock64();
+                for (int o = 32; o; o >>= 1) {
+                    it_near = max(it_near, (uint32_t)__shfl_xor((int)it_near, o));
+                    it_row = max(it_row, (uint32_t)__shfl_xor((int)it_row, o));
+                }
+                if (tid == 0) {
+                    atomicAdd(&g_deflate_t[8], tn1 - tn0);
+                    atomicAdd(&g_deflate_t[9], tn2 - tn1);
+                    atomicAdd(&g_deflate_t[10], (unsigned long long)it_near);
+                    atomicAdd(&g_deflate_t[11], (unsigned long long)it_row);
                 }
             }
             if (analysis && npairs < kPairs) mpp[npairs] = 0;
@@ -1210,7 +1344,7 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__rest
 }
 
 // Persistent workgroups: workgroup g compresses chunks g, g + gridDim.x, ...
-template <bool kOptimal>
+template <bool kOptimal, bool kChains>
 __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
@@ -1243,7 +1377,7 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
             continue;
         }
         uint32_t sz;
-        sz = compress_chunk<kOptimal>(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
+        sz = compress_chunk<kOptimal, kChains>(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
         if (threadIdx.x == 0) chunk_size[ch] = sz;
         WG_SYNC();
     }
@@ -1407,16 +1541,15 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     LevelParams lp = level_params(level);
     chunk_scan_kernel<<<1, 1024, 0, e->stream>>>(in_off, (uint32_t)n, chunk_first);
     (void)hipEventRecord(e->ev_begin, e->stream);
-    if (lp.optimal)
-        deflate_chunks_kernel<true><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
-                                                       (uint32_t)chunks, lp, scratch, stride, tokbuf,
-                                                       chunk_size, pairbuf, costbuf,
-                                                       flush == RSX_FLUSH_FINISH);
-    else
-        deflate_chunks_kernel<false><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,
-                                                       (uint32_t)chunks, lp, scratch, stride, tokbuf,
-                                                       chunk_size, pairbuf, costbuf,
-                                                       flush == RSX_FLUSH_FINISH);
+#define RSX_LAUNCH_CHUNKS(OPT, CH)                                                                        \
+    deflate_chunks_kernel<OPT, CH><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,     \
+                                                                (uint32_t)chunks, lp, scratch, stride, tokbuf, \
+                                                                chunk_size, pairbuf, costbuf,            \
+                                                                flush == RSX_FLUSH_FINISH)
+    if (lp.optimal) RSX_LAUNCH_CHUNKS(true, true);
+    else if (lp.chains) RSX_LAUNCH_CHUNKS(false, true);
+    else RSX_LAUNCH_CHUNKS(false, false);
+#undef RSX_LAUNCH_CHUNKS
     (void)hipEventRecord(e->ev_end, e->stream);
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
@@ -1424,9 +1557,11 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
         unsigned long long t[12];
         RSX_HIP(e, hipStreamSynchronize(e->stream));
         RSX_HIP(e, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_deflate_t), sizeof t));
-        fprintf(stderr, "[deflate] cycles/chunk: slide %.0f insert %.0f search %.0f parse %.0f emit %.0f flush %.0f (codes %.0f header %.0f)\n",
+        fprintf(stderr, "[deflate] cycles/chunk: slide %.0f insert %.0f search %.0f parse %.0f emit %.0f flush %.0f (codes %.0f header %.0f); "
+                        "wave 0: near %.0f rows %.0f cycles, %.1f near rounds and %.1f row rounds per batch\n",
                 t[0] / (double)chunks, t[1] / (double)chunks, t[2] / (double)chunks, t[3] / (double)chunks,
-                t[4] / (double)chunks, t[5] / (double)chunks, t[6] / (double)chunks, t[7] / (double)chunks);
+                t[4] / (double)chunks, t[5] / (double)chunks, t[6] / (double)chunks, t[7] / (double)chunks,
+                t[8] / (double)chunks, t[9] / (double)chunks, t[10] / (double)chunks / 256, t[11] / (double)chunks / 256);
         unsigned long long z[12] = {0};
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_deflate_t), z, sizeof z));
     }

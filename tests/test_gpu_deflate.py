@@ -187,3 +187,23 @@ def test_sizes_around_every_internal_boundary(eng, level):
     # and the same lengths again with the kinds rotated
     datas += [corpus.text(n, 990 + i) for i, n in enumerate(edges) if i % 4 != 0]
     roundtrip(eng, datas, 0, level)
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_one_large_buffer_in_each_container(eng, fmt):
+    """A batch of ONE 64 MiB text buffer (src/api.rs:22-57 with src/compress/mod.rs:699-772: the input is cut
+    into 256 chunks of 256 KiB, compressed in parallel and joined by sync-flush markers).  The stream must
+    inflate to the input with the oracle, with zlib and with the GPU inflater (one stream, one workgroup)."""
+    piece = 8 << 20
+    data = b"".join(corpus.text(piece, 500 + k) for k in range(8))
+    assert len(data) == 64 << 20
+    comp, status = eng.batch_compress([data], fmt, 6)
+    assert list(status) == [0]
+    c = comp[0]
+    assert len(c) <= o.compress_bound(fmt, len(data)) and len(c) < len(data) // 2
+    assert c.count(b"\x00\x00\xff\xff") >= 255          # the joints between the 256 chunks
+    assert zlib.decompress(c, WBITS[fmt]) == data
+    r, used, back = o.decompress(c, len(data), fmt)
+    assert (r, used) == (o.SUCCESS, len(c)) and back == data
+    back, st = eng.batch_decompress([c], [len(data)], fmt)
+    assert list(st) == [0] and back[0] == data
