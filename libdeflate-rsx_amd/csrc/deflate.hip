@@ -53,6 +53,9 @@ constexpr uint32_t kChunk = 256 * 1024;         // src/compress/mod.rs:699-700
 // the table does not depend on the order the lanes arrive in.  (The reference keeps hash chains,
 // matchfinder.rs:754-891: a chain is a serial walk of dependent loads, a row is read at once and
 // its tags drop nearly every candidate that is only a hash collision.)
+#ifndef RSX_STRAGGLERS
+#define RSX_STRAGGLERS 0
+#endif
 constexpr int kRowBits = 11;
 constexpr uint32_t kRows = 1u << kRowBits;
 constexpr uint32_t kWays = 12;
@@ -356,7 +359,7 @@ __device__ inline uint32_t token_bits(const ChunkLds &L, uint32_t t)
 #define RSX_DEV_TIMERS 0
 #endif
 // development timers (cycles summed over workgroups): slide, insert, search, parse, emit, flush
-__device__ unsigned long long g_deflate_t[12];
+__device__ unsigned long long g_deflate_t[16];
 #define DT_MARK(k) do { if (RSX_DEV_TIMERS && threadIdx.x == 0) { unsigned long long t_ = clock64(); dt[k] += t_ - tq; tq = t_; } } while (0)
 
 // exclusive prefix sum over the workgroup (returns the total through *total)
@@ -1030,22 +1033,30 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 best_len = better ? l : best_len;
                 best_off = better ? dist : best_off;
             };
-            uint32_t it_near = 0, it_row = 0;
+            uint32_t it_near = 0, it_row = 0, it_full = 0;
             unsigned long long tn0 = RSX_DEV_TIMERS ? clock64() : 0;
             // near distances: the candidate's first 20 bytes are the 8 bytes in front of p followed
             // by p's own, all in registers
-            if (near) {
+#ifdef RSX_SKIP_NEAR
+            near = 0;
+#endif
+            {
+                // (a loop over the set bits, nearest first: an unrolled test of every distance would
+                // run all eight bodies whenever any lane of the wave has that bit)
                 const uint32_t C[7] = {w0r, w1r, S[0], S[1], S[2], S[3], S[4]};
+                while (near && best_len < stop_len) {
+                    const uint32_t d = (uint32_t)__ffs((int)near) - 1;
+                    near &= near - 1;
+                    it_near++;
+                    // a candidate that differs from p at offset best_len cannot be longer
+                    if (best_len && L.inbuf[src_at - d + best_len] != L.inbuf[src_at + best_len]) continue;
+                    const uint32_t o = kNearDist - d;   // byte offset of position p - d in C
+                    const bool up = o >= 4;
+                    uint32_t w[5];
 #pragma unroll
-                for (uint32_t d = 1; d <= kNearDist; d++) {
-                    if ((near >> d) & 1) {
-                        const uint32_t o = kNearDist - d, i = o >> 2, sh = o & 3;
-                        uint32_t w[5];
-#pragma unroll
-                        for (uint32_t k = 0; k < 5; k++)
-                            w[k] = sh ? __builtin_amdgcn_alignbyte(C[i + k + 1], C[i + k], sh) : C[i + k];
-                        consider(finish_length(w, d), d);
-                    }
+                    for (uint32_t k = 0; k < 5; k++)
+                        w[k] = __builtin_amdgcn_alignbyte(up ? C[k + 2] : C[k + 1], up ? C[k + 1] : C[k], o);
+                    consider(finish_length(w, d), d);
                 }
             }
             unsigned long long tn1 = RSX_DEV_TIMERS ? clock64() : 0;
@@ -1071,20 +1082,27 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                     // window, of the search budget
                     go = best_len < stop_len && link != 0 && dist + link <= max_dist && depth < lp.max_depth;
                 }
+#ifdef RSX_SKIP_ROWS
+            } else if (false) {
+#else
             } else if (can4 && best_len < stop_len) {
+#endif
                 const uint4 *rp = reinterpret_cast<const uint4 *>(&L.rows[row * kWays]);
                 const uint4 ra = rp[0], rb = rp[1], rc = rp[2];
                 const uint32_t e[kWays] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z, rc.w};
                 static_assert(kWays == 12, "three 16-byte reads per row");
                 // candidates: entries with this position's tag that lie in front of it inside the
                 // window (another tag, an empty entry, this or a later position of the batch fall
-                // out), taken nearest first: key = distance << 4 | slot, ~0 = none
+                // out), taken nearest first.  (p + 1) << kTagBits | tag minus an entry with the same
+                // tag is distance << kTagBits; rotated right by kTagBits it is the distance, and
+                // with another tag a number far above any distance.  key = distance, ~0 = none.
+                const uint32_t mine = ((p + 1) << kTagBits) | tag;
                 uint32_t key[kWays];
 #pragma unroll
                 for (uint32_t k = 0; k < kWays; k++) {
-                    const uint32_t d = p + 1 - (e[k] >> kTagBits);
-                    const bool ok = ((e[k] ^ tag) & kTagMask) == 0 && d - 1 < max_dist;
-                    key[k] = ok ? (d << 4) | k : ~0u;
+                    const uint32_t t = mine - e[k];
+                    const uint32_t d = __builtin_amdgcn_alignbit(t, t, kTagBits);
+                    key[k] = d - 1 < max_dist ? d : ~0u;
                 }
                 uint32_t depth = 0;
                 // the byte a candidate must match to be longer than the best so far
@@ -1094,13 +1112,18 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
 #pragma unroll
                     for (uint32_t k = 1; k < kWays; k++) v = key[k] < v ? key[k] : v;
                     if (v == ~0u) break;
+                    // a wave does not go on for a handful of lanes: their remaining (farther)
+                    // candidates are dropped (the lanes of a wave are fixed positions, so this
+                    // depends on the data alone)
+                    if (depth >= 2 && __popcll(__ballot(true)) < RSX_STRAGGLERS) break;
 #pragma unroll
                     for (uint32_t k = 0; k < kWays; k++) key[k] = key[k] == v ? ~0u : key[k];
-                    const uint32_t d0 = v >> 4;
+                    const uint32_t d0 = v;
                     depth++;
                     it_row++;
                     if (best_len && L.inbuf[src_at - d0 + best_len] != next_byte) continue;
                     uint32_t w[5];
+                    it_full++;
                     lds_bytes<5>(L.inbuf, src_at - d0, w);
                     const uint32_t before_len = best_len;
                     consider(finish_length(w, d0), d0);
@@ -1109,9 +1132,16 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             }
             if (RSX_DEV_TIMERS) {
                 unsigned long long tn2 = clock64();
+                uint32_t sum_row = it_row, sum_full = it_full;
                 for (int o = 32; o; o >>= 1) {
                     it_near = max(it_near, (uint32_t)__shfl_xor((int)it_near, o));
                     it_row = max(it_row, (uint32_t)__shfl_xor((int)it_row, o));
+                    sum_row += (uint32_t)__shfl_xor((int)sum_row, o);
+                    sum_full += (uint32_t)__shfl_xor((int)sum_full, o);
+                }
+                if (tid == 0) {
+                    atomicAdd(&g_deflate_t[12], (unsigned long long)sum_row);
+                    atomicAdd(&g_deflate_t[13], (unsigned long long)sum_full);
                 }
                 if (tid == 0) {
                     atomicAdd(&g_deflate_t[8], tn1 - tn0);
@@ -1554,15 +1584,16 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
     if (RSX_DEV_TIMERS && getenv("RSX_DEFLATE_STATS")) {
-        unsigned long long t[12];
+        unsigned long long t[16];
         RSX_HIP(e, hipStreamSynchronize(e->stream));
         RSX_HIP(e, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_deflate_t), sizeof t));
         fprintf(stderr, "[deflate] cycles/chunk: slide %.0f insert %.0f search %.0f parse %.0f emit %.0f flush %.0f (codes %.0f header %.0f); "
-                        "wave 0: near %.0f rows %.0f cycles, %.1f near rounds and %.1f row rounds per batch\n",
+                        "wave 0: near %.0f rows %.0f cycles, %.1f near rounds and %.1f row rounds per batch, per lane %.2f candidates, %.2f compared in full\n",
                 t[0] / (double)chunks, t[1] / (double)chunks, t[2] / (double)chunks, t[3] / (double)chunks,
                 t[4] / (double)chunks, t[5] / (double)chunks, t[6] / (double)chunks, t[7] / (double)chunks,
-                t[8] / (double)chunks, t[9] / (double)chunks, t[10] / (double)chunks / 256, t[11] / (double)chunks / 256);
-        unsigned long long z[12] = {0};
+                t[8] / (double)chunks, t[9] / (double)chunks, t[10] / (double)chunks / 256, t[11] / (double)chunks / 256,
+                t[12] / (double)chunks / 256 / 64, t[13] / (double)chunks / 256 / 64);
+        unsigned long long z[16] = {0};
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_deflate_t), z, sizeof z));
     }
     if (format != RSX_FORMAT_DEFLATE) {

@@ -5,6 +5,9 @@
 //   4 b32 aligned, random dwords            5 b32 random bytes (unaligned)
 //   6 b64 aligned, random                   7 b64 random bytes (unaligned)
 //   8 b128 aligned, random 48-byte rows     9 3 x b32 aligned covering an unaligned b64, stride 1
+//  10 b64 store aligned, random            11 b64 store at random 2-byte offsets
+//  12 4 x b16 stores at random 2-byte offsets   13 b128 store at random 2-byte offsets
+//  14 u8 loads, random                     15 u16 loads, random
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +38,17 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, int iters)
             if (MODE == 6) acc += (uint32_t)*(uint64_t *)&lds[(r >> 16) & 0xFFF8];
             if (MODE == 7) acc += (uint32_t)*(u64u *)&lds[(r >> 16) & 0xFFFF];
             if (MODE == 8) { uint4 v = *(uint4 *)&lds[((r >> 16) % 1360) * 48]; acc += v.x ^ v.w; }
+            typedef __attribute__((aligned(2))) uint64_t u64h;
+            typedef __attribute__((aligned(2))) uint4 u128h;
+            if (MODE == 10) *(uint64_t *)&lds[(r >> 16) & 0xFFF8] = r;
+            if (MODE == 11) *(u64h *)&lds[(r >> 16) & 0xFFFE] = r;
+            if (MODE == 12) {
+                uint16_t *q = (uint16_t *)&lds[(r >> 16) & 0xFFFE];
+                q[0] = (uint16_t)r; q[1] = (uint16_t)(r >> 3); q[2] = (uint16_t)(r >> 5); q[3] = (uint16_t)(r >> 7);
+            }
+            if (MODE == 13) *(u128h *)&lds[(r >> 16) & 0xFFFE] = make_uint4(r, r + 1, r + 2, r + 3);
+            if (MODE == 14) acc += lds[(r >> 16) & 0xFFFF];
+            if (MODE == 15) acc += *(uint16_t *)&lds[(r >> 16) & 0xFFFE];
             if (MODE == 9) {
                 const uint32_t a = base + 1 + (threadIdx.x & 63) + 256 * (threadIdx.x >> 6);
                 const uint32_t *q = (const uint32_t *)&lds[a & ~3u];
@@ -43,7 +57,8 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, int iters)
             }
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    __syncthreads();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc + lds[threadIdx.x];
 }
 
 template <int MODE>
@@ -73,5 +88,7 @@ int main(int argc, char **argv)
     run<0>(out, wps, iters); run<1>(out, wps, iters); run<2>(out, wps, iters); run<3>(out, wps, iters);
     run<4>(out, wps, iters); run<5>(out, wps, iters); run<6>(out, wps, iters); run<7>(out, wps, iters);
     run<8>(out, wps, iters); run<9>(out, wps, iters);
+    run<10>(out, wps, iters); run<11>(out, wps, iters); run<12>(out, wps, iters); run<13>(out, wps, iters);
+    run<14>(out, wps, iters); run<15>(out, wps, iters);
     return 0;
 }
