@@ -68,7 +68,10 @@ constexpr int kHashBits = 13;                   // 2^13 heads (the reference has
 constexpr uint32_t kNearDist = 8;               // distances 1..kNearDist are checked from registers
 constexpr uint32_t kWindow = 32768;
 constexpr uint32_t kBlockSoft = 65535 - kCT - 300;  // close the block once it holds this many bytes
-constexpr uint32_t kTokCap = 66 * 1024;         // tokens per block (<= bytes per block)
+constexpr uint32_t kTokCap = 66 * 1024;         // 16-bit token units per block (<= bytes per block)
+// Bit output: one round of packing (two token units per lane, at most 28 bits each) plus the 16-byte
+// unit the round before left open are staged in LDS and leave it as whole 16-byte stores.
+constexpr uint32_t kStageWords = 2 * kCT * 28 / 32 + 64;
 constexpr uint32_t kPairs = 8;                  // recorded matches per position (levels 10-12)
 constexpr uint32_t kMaxBlocks = 8;              // blocks per chunk
 constexpr uint32_t kSegment = 8192;             // positions per piece of the cost-based parse (at least)
@@ -140,7 +143,8 @@ struct __align__(16) ChunkLds {
     };
     uint16_t m_len[kCT + 2];         // best match per parse slot: slot 0 = last position of the
     uint16_t m_off[kCT + 2];         //   previous batch, slots 1..kCT = this batch
-    uint16_t jump[2][kCT + 2];       // pointer-jumping tables (slot -> slot, kCT+1 = past the end)
+    alignas(16) uint16_t jump[2][kCT + 2];   // pointer-jumping tables (slot -> slot, kCT+1 = past the end)
+    alignas(16) uint16_t tok_tail[8];        // token units behind the last complete 16-byte piece of the token buffer
     uint8_t mark[kCT + 2];
     uint8_t len_slot[260];
     uint32_t litlen_freq[288], off_freq[32];
@@ -148,11 +152,13 @@ struct __align__(16) ChunkLds {
     uint8_t litlen_len[288], off_len[32];
     uint32_t scan_tmp[kCT / 64 * 2];
     // control (written by one lane between barriers)
-    uint32_t block_ntok;      // tokens in the open block
+    uint32_t block_ntok;      // 16-bit token units in the open block
     uint32_t entry;           // chunk position of the next token start
     uint32_t block_start;     // chunk position where the open block starts
     uint32_t next_entry;      // scratch for the parse hand-over
     uint64_t out_bits;        // bits written to the chunk output so far
+    uint32_t stage_word0;     // output word that stage[0] stands for (a multiple of 4)
+    uint32_t stage[kStageWords];   // output words [stage_word0, ...): bits are OR-ed in, then flushed
     uint32_t huff_scratch[288 + 32];
     uint32_t len_counts[2][16];
     uint32_t huff_flag[2];           // an alphabet needs the length-limiting walk
@@ -165,17 +171,62 @@ struct __align__(16) ChunkLds {
     uint32_t cut[kMaxCuts], ncut;         // ends of the pieces of the cost-based parse; bit 31 = also a block end  // first lanes of the runs of equal code lengths
 };
 
-// ---- bit output: the chunk scratch is zeroed up front, every write is an OR ----
+// ---- bit output -------------------------------------------------------------------
+// Token units (16 bits each, in the workgroup's token buffer): a literal is its byte value, a
+// match is a length unit kUnitLen | (len - 3) followed by a distance unit kUnitDist | (dist - 1).
+constexpr uint32_t kUnitLen = 0x4000, kUnitDist = 0x8000;
 
-__device__ inline void or_bits(uint32_t *words, uint64_t bitpos, uint64_t value, uint32_t nbits)
+// Any lane: OR `nbits` (<= 57) bits of `value` into the stage at absolute bit position `pos` of
+// the chunk output.  The position must lie inside the staged window.
+__device__ inline void stage_or(ChunkLds &L, uint64_t pos, uint64_t value, uint32_t nbits)
 {
     if (nbits == 0) return;
-    uint64_t w = bitpos >> 5;
-    uint32_t sh = (uint32_t)(bitpos & 31);
-    // value < 2^nbits, nbits <= 32: spans at most two words
-    uint64_t v = value << sh;
-    atomicOr(&words[w], (uint32_t)v);
-    if (sh + nbits > 32) atomicOr(&words[w + 1], (uint32_t)(v >> 32));
+    const uint32_t w = (uint32_t)(pos >> 5) - L.stage_word0, sh = (uint32_t)(pos & 31);
+    const uint64_t lo = value << sh;
+    atomicOr(&L.stage[w], (uint32_t)lo);
+    if (sh + nbits > 32) atomicOr(&L.stage[w + 1], (uint32_t)(lo >> 32));
+    if (sh + nbits > 64) atomicOr(&L.stage[w + 2], (uint32_t)(value >> (64 - sh)));
+}
+
+// All lanes, behind a barrier that follows the ORs: the complete 16-byte units below bit
+// `upto` go to the output with plain stores, the unit that is still open moves to the front of
+// the stage and the rest of the stage is cleared.
+__device__ inline void stage_flush(ChunkLds &L, uint32_t *out_words, uint64_t upto)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t w0 = L.stage_word0;
+    const uint32_t full = (uint32_t)(upto >> 7) - (w0 >> 2);   // (< kStageWords / 4 <= kCT)
+    uint4 *st = reinterpret_cast<uint4 *>(L.stage);
+    uint4 tail = make_uint4(0, 0, 0, 0);
+#ifndef RSX_NO_OUTSTORE
+    if (tid < full) reinterpret_cast<uint4 *>(out_words + w0)[tid] = st[tid];
+#endif
+    if (tid == 0) tail = st[full];
+    WG_SYNC();
+    if (tid <= full) st[tid] = tail;   // (zero except on lane 0)
+    if (tid == 0) L.stage_word0 = w0 + 4 * full;
+    WG_SYNC();
+}
+
+// All lanes: `count` bytes of the input from `src` as they are, at the byte-aligned bit
+// position L.out_bits (stored blocks).
+__device__ inline void stage_bytes(ChunkLds &L, uint32_t *out_words, const uint8_t *src, uint32_t count)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t base = 0; base < count; base += 4 * kCT) {
+        const uint64_t pos = L.out_bits;   // (bits of the rounds before included)
+        const uint32_t at = base + 4 * tid;
+        if (at < count) {
+            const uint32_t nb = count - at < 4 ? count - at : 4;
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < nb; k++) v |= (uint32_t)src[at + k] << (8 * k);
+            stage_or(L, pos + 32ull * tid, v, 8 * nb);
+        }
+        WG_SYNC();
+        const uint32_t done = count - base < 4 * kCT ? count - base : 4 * kCT;
+        if (tid == 0) L.out_bits = pos + 8ull * done;
+        stage_flush(L, out_words, pos + 8ull * done);
+    }
 }
 
 // ---- Huffman code construction (src/compress/huffman_comp.rs) spread over the workgroup ----
@@ -346,15 +397,6 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
     WG_SYNC();
 }
 
-// bits of one token under the open block's codes
-__device__ inline uint32_t token_bits(const ChunkLds &L, uint32_t t)
-{
-    if (!(t & 0x80000000u)) return L.litlen_len[t & 0xFF];
-    uint32_t len = (t & 0xFF) + 3, dist = ((t >> 8) & 0x7FFF) + 1;
-    uint32_t ls = L.len_slot[len], os = offset_slot(dist);
-    return L.litlen_len[257 + ls] + k_len_extra[ls] + L.off_len[os] + k_off_extra[os];
-}
-
 #ifndef RSX_DEV_TIMERS
 #define RSX_DEV_TIMERS 0
 #endif
@@ -419,8 +461,8 @@ __device__ inline uint32_t precode_extra_bits(uint32_t sym) { return sym == 16 ?
 // All lanes: Huffman codes of the open block, the block type decision (src/compress/mod.rs:
 // 1375-1398), its header (mod.rs:1775-1883), the tokens, and a fresh block state.
 // in = chunk input, tok = this workgroup's token buffer.
-__device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, bool is_final,
-                            const uint32_t *tok, uint32_t *out_words)
+__device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, bool is_final,
+                            const uint16_t *tok, uint32_t *out_words)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t ntok = L.block_ntok;
@@ -529,77 +571,66 @@ __device__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, 
         // stored block (src/compress/mod.rs:1408-1448): header bits, align, LEN, NLEN, bytes
         const uint64_t p = (pos + 3 + 7) & ~7ull;
         if (tid == 0) {
-            or_bits(out_words, pos, is_final ? 1 : 0, 3);
-            or_bits(out_words, p, block_bytes, 16);
-            or_bits(out_words, p + 16, (~block_bytes) & 0xFFFF, 16);
-            L.out_bits = p + 32 + 8ull * block_bytes;
+            stage_or(L, pos, is_final ? 1 : 0, 3);
+            stage_or(L, p, block_bytes | ((~block_bytes & 0xFFFF) << 16), 32);
+            L.out_bits = p + 32;
         }
-        uint8_t *ob = reinterpret_cast<uint8_t *>(out_words) + ((p + 32) >> 3);
-        for (uint32_t k = tid; k < block_bytes; k += kCT) ob[k] = in[bstart + k];
+        WG_SYNC();
+        stage_flush(L, out_words, p + 32);
+        stage_bytes(L, out_words, in + bstart, block_bytes);
     } else {
-        if (tid == 0) {
-            or_bits(out_words, pos, (is_final ? 1 : 0) | (2 << 1), 3);
-            or_bits(out_words, pos + 3, nl - 257, 5);
-            or_bits(out_words, pos + 8, no - 1, 5);
-            or_bits(out_words, pos + 13, np - 4, 4);
-        }
-        if (tid < np) or_bits(out_words, pos + 17 + 3 * tid, L.pre_len[k_precode_perm[tid]], 3);
+        if (tid == 0) stage_or(L, pos, (is_final ? 1 : 0) | (2 << 1) | ((nl - 257) << 3) | ((no - 1) << 8) | ((np - 4) << 13), 17);
+        if (tid < np) stage_or(L, pos + 17 + 3 * tid, L.pre_len[k_precode_perm[tid]], 3);
         if (tid < nitems) {
             const uint32_t sym = it >> 8, l = L.pre_len[sym];
-            or_bits(out_words, pos + 17 + 3 * np + ipos, L.pre_code[sym] | ((it & 0xFF) << l),
-                    l + precode_extra_bits(sym));
+            stage_or(L, pos + 17 + 3 * np + ipos, L.pre_code[sym] | ((it & 0xFF) << l), l + precode_extra_bits(sym));
         }
-        const uint64_t body0 = pos + hdr_bits;
-        // each lane packs a contiguous run of tokens
-        const uint32_t per = (ntok + kCT - 1) / kCT;
-        const uint32_t r0 = tid * per < ntok ? tid * per : ntok;
-        const uint32_t r1 = r0 + per < ntok ? r0 + per : ntok;
-        uint32_t bits = 0;
-        for (uint32_t i = r0; i < r1; i++) bits += token_bits(L, tok[i]);
-        uint32_t tbits;
-        uint32_t off = wg_exclusive_scan(L, bits, &tbits);
-        // The lane owns every output word that lies wholly inside its run of bits and
-        // writes those with plain stores; only its first and last word can be shared with
-        // a neighbour (or the header) and are OR-ed in.
-        {
-            const uint64_t p = body0 + off;
-            uint32_t *wp = out_words + (p >> 5);
-            uint32_t nb = (uint32_t)(p & 31);   // bits below belong to someone else: stay 0 here
-            uint64_t acc = 0;
-            bool first = true;
-            auto put = [&](uint32_t code, uint32_t len) {
-                acc |= (uint64_t)code << nb;
-                nb += len;
-                if (nb >= 32) {
-                    if (first) atomicOr(wp, (uint32_t)acc);
-                    else *wp = (uint32_t)acc;
-                    first = false;
-                    wp++;
-                    acc >>= 32;
-                    nb -= 32;
-                }
-            };
-            for (uint32_t i = r0; i < r1; i++) {
-                const uint32_t t = tok[i];
-                if (!(t & 0x80000000u)) {
-                    const uint32_t s = t & 0xFF;
-                    put(L.litlen_code[s], L.litlen_len[s]);
-                } else {
-                    const uint32_t len = (t & 0xFF) + 3, dist = ((t >> 8) & 0x7FFF) + 1;
-                    const uint32_t ls = L.len_slot[len], os = offset_slot(dist);
-                    const uint32_t l1 = L.litlen_len[257 + ls];
-                    put(L.litlen_code[257 + ls] | ((len - k_len_base[ls]) << l1), l1 + k_len_extra[ls]);
-                    const uint32_t l2 = L.off_len[os];
-                    put(L.off_code[os] | ((dist - k_off_base[os]) << l2), l2 + k_off_extra[os]);
+        WG_SYNC();
+        uint64_t at_bits = pos + hdr_bits;
+        stage_flush(L, out_words, at_bits);
+        // Rounds of two token units per lane: code bits in registers, a prefix sum of the lanes'
+        // bit counts, one OR of up to 56 bits into the stage, a flush of the complete units.
+        for (uint32_t base = 0; base < ntok; base += 2 * kCT) {
+            const uint32_t i0 = base + 2 * tid;
+            uint64_t val = 0;
+            uint32_t nb = 0;
+            if (i0 < ntok) {
+                const uint32_t pair = *reinterpret_cast<const uint32_t *>(tok + i0);   // (i0 is even)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t u = h ? pair >> 16 : pair & 0xFFFF;
+                    if (i0 + h < ntok) {
+                        uint32_t code, len;
+                        if (u & kUnitDist) {
+                            const uint32_t dist = (u & 0x7FFF) + 1, os = offset_slot(dist), l2 = L.off_len[os];
+                            code = L.off_code[os] | ((dist - k_off_base[os]) << l2);
+                            len = l2 + k_off_extra[os];
+                        } else if (u & kUnitLen) {
+                            const uint32_t ml = (u & 0xFF) + 3, ls = L.len_slot[ml], l1 = L.litlen_len[257 + ls];
+                            code = L.litlen_code[257 + ls] | ((ml - k_len_base[ls]) << l1);
+                            len = l1 + k_len_extra[ls];
+                        } else {
+                            code = L.litlen_code[u];
+                            len = L.litlen_len[u];
+                        }
+                        val |= (uint64_t)code << nb;
+                        nb += len;
+                    }
                 }
             }
-            if (acc) atomicOr(wp, (uint32_t)acc);
+            uint32_t round_bits;
+            const uint32_t off = wg_exclusive_scan(L, nb, &round_bits);
+            stage_or(L, at_bits + off, val, nb);
+            WG_SYNC();
+            at_bits += round_bits;
+            stage_flush(L, out_words, at_bits);
         }
         if (tid == 0) {
-            uint64_t e = body0 + tbits;
-            or_bits(out_words, e, L.litlen_code[256], L.litlen_len[256]);
-            L.out_bits = e + L.litlen_len[256];
+            stage_or(L, at_bits, L.litlen_code[256], L.litlen_len[256]);
+            L.out_bits = at_bits + L.litlen_len[256];
         }
+        WG_SYNC();
+        stage_flush(L, out_words, at_bits + L.litlen_len[256]);
     }
     WG_SYNC();
     // reset the block state
@@ -801,15 +832,13 @@ __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, u
 // replay code out of the kernel of the other levels
 template <bool kOptimal, bool kChains>
 __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, bool last_chunk,
-                                   LevelParams lp, uint32_t *tok, uint32_t *out_words, uint32_t *mp,
+                                   LevelParams lp, uint16_t *tok, uint32_t *out_words, uint32_t *mp,
                                    uint8_t *blkcost)
 {
     const int tid = threadIdx.x;
-    // zero the output region (all later writes are ORs), reset the tables
+    // reset the tables and the output stage
     {
-        uint4 *z = reinterpret_cast<uint4 *>(out_words);
-        const uint32_t units = (n + kScratchPad) / 16;
-        for (uint32_t u = tid; u < units; u += kCT) z[u] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < kStageWords; i += kCT) L.stage[i] = 0;
         for (uint32_t i = tid; i < (kChains ? (1u << kHashBits) : kRows * kWays) / 4; i += kCT)
             reinterpret_cast<uint4 *>(L.rows)[i] = make_uint4(0, 0, 0, 0);   // (the chain heads lie in front)
         for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
@@ -824,6 +853,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.entry = 0;
             L.block_start = 0;
             L.out_bits = 0;
+            L.stage_word0 = 0;
             L.m_len[0] = 0;
             L.m_off[0] = 0;
             L.nblk = 0;
@@ -841,7 +871,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
     if (n == 0) {
         // an empty input is an empty final fixed-Huffman block: BFINAL=1, BTYPE=01, end-of-block (7 zero bits)
         if (tid == 0) {
-            if (last_chunk) or_bits(out_words, 0, 3, 3);
+            if (last_chunk) stage_or(L, 0, 3, 3);
             L.out_bits = last_chunk ? 10 : 0;
         }
         WG_SYNC();
@@ -851,20 +881,16 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         // level 0: stored blocks only (src/compress/mod.rs:1400-1449)
         for (uint32_t pos = 0; pos < n; pos += 65535) {
             const uint32_t blen = n - pos < 65535 ? n - pos : 65535;
+            const uint64_t q0 = L.out_bits, q = (q0 + 3 + 7) & ~7ull;
+            WG_SYNC();   // everyone has read out_bits
             if (tid == 0) {
-                uint64_t q = L.out_bits;
-                or_bits(out_words, q, (last_chunk && pos + blen >= n) ? 1 : 0, 3);
-                q = (q + 3 + 7) & ~7ull;
-                or_bits(out_words, q, blen, 16);
-                or_bits(out_words, q + 16, (~blen) & 0xFFFF, 16);
+                stage_or(L, q0, (last_chunk && pos + blen >= n) ? 1 : 0, 3);
+                stage_or(L, q, blen | ((~blen & 0xFFFF) << 16), 32);
                 L.out_bits = q + 32;
             }
             WG_SYNC();
-            uint8_t *ob = reinterpret_cast<uint8_t *>(out_words) + (L.out_bits >> 3);
-            for (uint32_t k = tid; k < blen; k += kCT) ob[k] = in[pos + k];
-            WG_SYNC();
-            if (tid == 0) L.out_bits += 8ull * blen;
-            WG_SYNC();
+            stage_flush(L, out_words, q + 32);
+            stage_bytes(L, out_words, in + pos, blen);
         }
         n = 0;  // nothing left for the matcher
     }
@@ -912,19 +938,18 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         // ---- slide the LDS input window when the batch (plus the longest match) would
         //      run off its end; 32 KiB of history stay behind b0 ---------------------------
         if (!replay && b0 + kCT + 258 + 8 > w0 + kInBuf - 16 && staged < n) {
-            constexpr uint32_t kUnits = (kInBuf - kInSlide) / 16, kPer = (kUnits + kCT - 1) / kCT;
-            uint4 v[kPer];
-#pragma unroll
-            for (uint32_t k = 0; k < kPer; k++) {
-                uint32_t u = tid + k * kCT;
-                if (u < kUnits) v[k] = reinterpret_cast<const uint4 *>(L.inbuf)[u + kInSlide / 16];
-            }
+            constexpr uint32_t kUnits = (kInBuf - kInSlide) / 16;
+            static_assert(kUnits <= 3 * kCT, "three 16-byte units per lane");
+            const uint4 *from = reinterpret_cast<const uint4 *>(L.inbuf) + kInSlide / 16;
+            uint4 *to = reinterpret_cast<uint4 *>(L.inbuf);
+            const uint32_t u0 = tid, u1 = tid + kCT, u2 = tid + 2 * kCT;
+            // (named registers: an indexed array of three ends up in scratch memory here)
+            uint4 va = from[u0], vb = from[u1], vc = make_uint4(0, 0, 0, 0);
+            if (u2 < kUnits) vc = from[u2];
             WG_SYNC();
-#pragma unroll
-            for (uint32_t k = 0; k < kPer; k++) {
-                uint32_t u = tid + k * kCT;
-                if (u < kUnits) reinterpret_cast<uint4 *>(L.inbuf)[u] = v[k];
-            }
+            to[u0] = va;
+            to[u1] = vb;
+            if (u2 < kUnits) to[u2] = vc;
             w0 += kInSlide;
             WG_SYNC();
             const uint32_t upto = w0 + kInBuf - 16 < n ? w0 + kInBuf - 16 : n;
@@ -1253,13 +1278,33 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         // emit the tokens of marked slots in position order
         const bool live = tid < lim && L.mark[tid] != 0;
         const bool livex = tid == kCT - 1 && lim == kCT + 1 && L.mark[kCT] != 0;
-        uint32_t cnt = (live ? ntoks : 0) + (livex ? x_ntoks : 0);
+        // 16-bit units: one per literal, two per match
+        auto units_of = [](uint32_t t) -> uint32_t { return t >> 31 ? 2u : 1u; };
+        // The batch's units are collected in LDS (the pointer-jumping tables are idle by now) and
+        // leave it as whole 16-byte pieces: two-byte stores scattered over the lanes cost several
+        // times their size in write traffic.  The stage starts with the units the batch before
+        // left behind its last complete piece, so a piece of the stage is a piece of the buffer.
+        // A position holds at most one unit on average (a literal: one unit per byte, a match:
+        // two per three bytes or more).
+        uint16_t *ustage = reinterpret_cast<uint16_t *>(L.jump);
+        static_assert(sizeof(L.jump) >= (kCT + 32) * 2, "one batch of token units");
+        auto put_units = [&](uint32_t at, uint32_t t) {
+            if (t >> 31) {
+                ustage[at] = (uint16_t)(kUnitLen | (t & 0xFF));
+                ustage[at + 1] = (uint16_t)(kUnitDist | ((t >> 8) & 0x7FFF));
+            } else {
+                ustage[at] = (uint16_t)t;
+            }
+        };
+        const uint32_t my_units = live ? units_of(t0) + (ntoks == 2 ? units_of(t1) : 0) : 0;
+        uint32_t cnt = my_units + (livex ? units_of(x_t0) : 0);
         uint32_t total;
         uint32_t at = wg_exclusive_scan(L, cnt, &total);
-        const uint32_t tbase = L.block_ntok;
+        const uint32_t tbase = L.block_ntok, ta = tbase & 7;
+        if ((uint32_t)tid < ta) ustage[tid] = L.tok_tail[tid];
         if (live) {
-            tok[tbase + at] = t0;
-            if (ntoks == 2) tok[tbase + at + 1] = t1;
+            put_units(ta + at, t0);
+            if (ntoks == 2) put_units(ta + at + units_of(t0), t1);
             // histograms (compress/mod.rs:1306-1351)
             uint32_t tt = ntoks == 2 ? t1 : t0;
             if (ntoks == 2 || !(t0 & 0x80000000u)) atomicAdd(&L.litlen_freq[t0 & 0xFF], 1u);
@@ -1272,7 +1317,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             if (my_next >= lim) L.next_entry = base_pos + my_next;
         }
         if (livex) {
-            tok[tbase + at + (live ? ntoks : 0)] = x_t0;
+            put_units(ta + at + my_units, x_t0);
             if (x_t0 & 0x80000000u) {
                 uint32_t len = (x_t0 & 0xFF) + 3, dist = ((x_t0 >> 8) & 0x7FFF) + 1;
                 atomicAdd(&L.litlen_freq[257 + L.len_slot[len]], 1u);
@@ -1283,6 +1328,14 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.next_entry = base_pos + x_next;
         }
         WG_SYNC();
+        {
+            // pieces of the stage -> tok[tbase - ta ...], 16 bytes per lane (the last one may end in
+            // units that are not there yet: the next batch writes that piece again)
+            const uint32_t have = ta + total, pieces = (have + 7) >> 3;   // (<= (kCT + 32) / 8)
+            if ((uint32_t)tid < pieces)
+                reinterpret_cast<uint4 *>(tok + (tbase - ta))[tid] = reinterpret_cast<const uint4 *>(ustage)[tid];
+            if ((uint32_t)tid < (have & 7)) L.tok_tail[tid] = ustage[(have & ~7u) + tid];
+        }
         if (tid == 0) {
             if (total) L.entry = L.next_entry;
             L.block_ntok = tbase + total;
@@ -1304,7 +1357,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 b0 += kCT;
             }
         } else {
-            if (tail || covered - L.block_start >= kBlockSoft || L.block_ntok + 2 * kCT + 2 > kTokCap) {
+            if (tail || covered - L.block_start >= kBlockSoft || L.block_ntok + 3 * kCT + 4 > kTokCap) {
                 const uint32_t block_end = tail ? n : covered;
                 if (analysis) record_block(L, block_end, blkcost);
                 else flush_block(L, in, block_end, tail && last_chunk, tok, out_words);
@@ -1326,18 +1379,19 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         for (int k = 0; k < 6; k++) atomicAdd(&g_deflate_t[k], dt[k]);
 
     // chunk trailer: sync flush between chunks (src/compress/mod.rs:662-681)
-    if (tid == 0) {
-        uint64_t p = L.out_bits;
-        if (!last_chunk) {
-            p = (p + 3 + 7) & ~7ull;     // empty stored block header, byte aligned
-            or_bits(out_words, p, 0xFFFF0000u, 32);
-            p += 32;
-        } else {
-            p = (p + 7) & ~7ull;
+    {
+        const uint64_t p0 = L.out_bits;
+        const uint64_t p = last_chunk ? (p0 + 7) & ~7ull : ((p0 + 3 + 7) & ~7ull) + 32;
+        WG_SYNC();   // everyone has read out_bits
+        if (tid == 0) {
+            if (!last_chunk) stage_or(L, p - 32, 0xFFFF0000u, 32);   // empty stored block header, byte aligned
+            L.out_bits = p;
         }
-        L.out_bits = p;
+        WG_SYNC();
+        stage_flush(L, out_words, p);
+        // the unit that is still open (zero bits behind the last byte)
+        if (tid == 0) reinterpret_cast<uint4 *>(out_words + L.stage_word0)[0] = reinterpret_cast<uint4 *>(L.stage)[0];
     }
-    WG_SYNC();
     return (uint32_t)(L.out_bits >> 3);
 }
 
@@ -1378,7 +1432,7 @@ template <bool kOptimal, bool kChains>
 __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
-    uint8_t *__restrict__ scratch, uint64_t scratch_stride, uint32_t *__restrict__ tokbuf,
+    uint8_t *__restrict__ scratch, uint64_t scratch_stride, uint16_t *__restrict__ tokbuf,
     uint32_t *__restrict__ chunk_size, uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf,
     int finish)
 {
@@ -1386,7 +1440,7 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     uint32_t *mp = pairbuf ? pairbuf + (size_t)blockIdx.x * kChunk * kPairs : nullptr;
     uint8_t *blkcost = costbuf + (size_t)blockIdx.x * kMaxBlocks * kBlkCostStride;
     const uint32_t total_chunks = chunk_first[n];
-    uint32_t *tok = tokbuf + (size_t)blockIdx.x * kTokCap;
+    uint16_t *tok = tokbuf + (size_t)blockIdx.x * kTokCap;
     for (uint32_t ch = blockIdx.x; ch < total_chunks && ch < chunk_slots; ch += gridDim.x) {
         uint32_t lo = 0, hi = n;   // item with chunk_first[item] <= ch < chunk_first[item+1]
         while (hi - lo > 1) {
@@ -1413,24 +1467,51 @@ __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     }
 }
 
-// One workgroup per item: container header, the item's chunks back to back, trailer.
-__global__ __launch_bounds__(256) void deflate_gather_kernel(
+// ---- gather: the item's chunks back to back behind the container header, then the trailer ----
+// deflate_plan_kernel (one workgroup per item) sizes the item, chooses between its compressed
+// chunks and plain stored blocks, writes header, trailer, size and status and gives every chunk
+// its place in the output; deflate_place_kernel (one workgroup per chunk) moves the bytes, so one
+// large item is copied by as many workgroups as it has chunks.
+
+constexpr uint32_t kModeChunks = 0, kModeStored = 1, kModeFailed = 2;
+
+__global__ __launch_bounds__(256) void deflate_plan_kernel(
     int format, int level, const uint64_t *__restrict__ in_off, uint32_t n,
-    const uint32_t *__restrict__ chunk_first, const uint8_t *__restrict__ scratch,
-    uint64_t scratch_stride, const uint32_t *__restrict__ chunk_size,
+    const uint32_t *__restrict__ chunk_first, const uint32_t *__restrict__ chunk_size,
     const uint32_t *__restrict__ sums, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
-    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, const uint8_t *__restrict__ in,
-    int finish)
+    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ chunk_dst,
+    uint32_t *__restrict__ item_mode, int finish)
 {
-    const uint32_t item = blockIdx.x;
+    __shared__ uint64_t wsum[4];
+    __shared__ uint64_t carry;
+    const uint32_t item = blockIdx.x, tid = threadIdx.x;
     if (item >= n) return;
     const uint32_t c0 = chunk_first[item], c1 = chunk_first[item + 1];
     const uint64_t slot = out_off[item + 1] - out_off[item];
     uint8_t *o = out + out_off[item];
     const uint32_t hdr = format == RSX_FORMAT_ZLIB ? 2 : format == RSX_FORMAT_GZIP ? 10 : 0;
     const uint32_t trl = format == RSX_FORMAT_ZLIB ? 4 : format == RSX_FORMAT_GZIP ? 8 : 0;
-    uint64_t total = hdr + trl;
-    for (uint32_t c = c0; c < c1; c++) total += chunk_size[c];
+    // exclusive prefix of the chunk sizes -> place of every chunk behind the header
+    if (tid == 0) carry = hdr;
+    __syncthreads();
+    for (uint32_t base = c0; base < c1; base += 256) {
+        const uint32_t c = base + tid;
+        const uint64_t v = c < c1 ? chunk_size[c] : 0;
+        uint64_t x = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t y = __shfl_up(x, d);
+            if ((int)(tid & 63) >= d) x += y;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = x;
+        __syncthreads();
+        uint64_t before = carry;
+        for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
+        if (c < c1) chunk_dst[c] = before + x - v;
+        __syncthreads();
+        if (tid == 255) carry = before + x;
+        __syncthreads();
+    }
+    uint64_t total = carry + trl;
     // The whole item as stored blocks of 65535 bytes (the level-0 format,
     // src/compress/mod.rs:1400-1464) when that is smaller: incompressible items then fit the
     // compress bound however many chunks they have (a chunk of stored blocks pays for a short
@@ -1441,45 +1522,21 @@ __global__ __launch_bounds__(256) void deflate_gather_kernel(
     const bool stored = stored_total <= slot && (total > slot || stored_total < total);
     if (total > slot && !stored) {
         // CompressResult::InsufficientSpace (src/compress/mod.rs:756-758)
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             status[item] = RSX_COMPRESS_INSUFFICIENT_SPACE;
             out_sizes[item] = 0;
+            item_mode[item] = kModeFailed;
         }
         return;
     }
-    uint64_t at = hdr;
-    if (stored) {
-        const uint8_t *src = in + in_off[item];
-        for (uint64_t b = 0; b < nblk; b++) {
-            const uint64_t pos = b * 65535;
-            const uint32_t blen = (uint32_t)(ilen - pos < 65535 ? ilen - pos : 65535);
-            uint8_t *q = o + at;
-            if (threadIdx.x == 0) {
-                q[0] = (finish && b == nblk - 1) ? 1 : 0;
-                q[1] = (uint8_t)blen;
-                q[2] = (uint8_t)(blen >> 8);
-                q[3] = (uint8_t)~blen;
-                q[4] = (uint8_t)(~blen >> 8);
-            }
-            for (uint32_t k = threadIdx.x; k < blen; k += blockDim.x) q[5 + k] = src[pos + k];
-            at += 5 + blen;
+    if (stored) total = stored_total;
+    if (tid == 0) {
+        item_mode[item] = stored ? kModeStored : kModeChunks;
+        uint64_t at = total - trl;
+        if (stored && !finish) {
+            uint8_t *q = o + at - 5;
+            q[0] = 0; q[1] = 0; q[2] = 0; q[3] = 0xFF; q[4] = 0xFF;
         }
-        if (!finish) {
-            if (threadIdx.x == 0) {
-                o[at] = 0; o[at + 1] = 0; o[at + 2] = 0; o[at + 3] = 0xFF; o[at + 4] = 0xFF;
-            }
-            at += 5;
-        }
-        total = stored_total;
-    } else {
-        for (uint32_t c = c0; c < c1; c++) {
-            const uint8_t *s = scratch + (size_t)c * scratch_stride;
-            const uint32_t sz = chunk_size[c];
-            for (uint32_t k = threadIdx.x; k < sz; k += blockDim.x) o[at + k] = s[k];
-            at += sz;
-        }
-    }
-    if (threadIdx.x == 0) {
         if (format == RSX_FORMAT_ZLIB) {
             // src/compress/mod.rs:2257-2269, :2288-2296
             uint32_t h = (8u << 8) | (7u << 12);
@@ -1510,6 +1567,71 @@ __global__ __launch_bounds__(256) void deflate_gather_kernel(
     }
 }
 
+// All lanes of a workgroup: count bytes from src to dst, any alignment on both sides: the
+// destination is written as aligned dwords made of two aligned source dwords.
+__device__ inline void copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t count)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    uint64_t head = (4 - ((uintptr_t)dst & 3)) & 3;
+    if (head > count) head = count;
+    if (tid < head) dst[tid] = src[tid];
+    const uint64_t ndw = (count - head) >> 2;
+    const uint8_t *s = src + head;
+    const uint32_t sh = (uint32_t)((uintptr_t)s & 3);
+    const uint32_t *sa = reinterpret_cast<const uint32_t *>(s - sh);
+    uint32_t *da = reinterpret_cast<uint32_t *>(dst + head);
+    if (sh == 0) {
+        for (uint64_t j = tid; j < ndw; j += nt) da[j] = sa[j];
+    } else {
+        // (the dword behind the last one needed holds at least one byte of the range: no read past it)
+        for (uint64_t j = tid; j < ndw; j += nt) da[j] = __builtin_amdgcn_alignbyte(sa[j + 1], sa[j], sh);
+    }
+    const uint64_t done = head + 4 * ndw;
+    if (tid < count - done) dst[done + tid] = src[done + tid];
+}
+
+__global__ __launch_bounds__(256) void deflate_place_kernel(
+    const uint64_t *__restrict__ in_off, uint32_t n, const uint32_t *__restrict__ chunk_first,
+    uint32_t chunk_slots, const uint8_t *__restrict__ scratch, uint64_t scratch_stride,
+    const uint32_t *__restrict__ chunk_size, const uint64_t *__restrict__ chunk_dst,
+    const uint32_t *__restrict__ item_mode, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+    const uint8_t *__restrict__ in, int format, int finish)
+{
+    const uint32_t total_chunks = chunk_first[n];
+    for (uint32_t ch = blockIdx.x; ch < total_chunks && ch < chunk_slots; ch += gridDim.x) {
+        uint32_t lo = 0, hi = n;   // item with chunk_first[item] <= ch < chunk_first[item+1]
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (chunk_first[mid] <= ch) lo = mid; else hi = mid;
+        }
+        const uint32_t item = lo, mode = item_mode[item];
+        uint8_t *o = out + out_off[item];
+        if (mode == kModeChunks) {
+            copy_bytes(o + chunk_dst[ch], scratch + (size_t)ch * scratch_stride, chunk_size[ch]);
+        } else if (mode == kModeStored) {
+            // stored blocks k, k + chunks, ... of the item
+            const uint32_t hdr = format == RSX_FORMAT_ZLIB ? 2 : format == RSX_FORMAT_GZIP ? 10 : 0;
+            const uint32_t k = ch - chunk_first[item], step = chunk_first[item + 1] - chunk_first[item];
+            const uint64_t ilen = in_off[item + 1] - in_off[item];
+            const uint64_t nblk = ilen ? (ilen + 65534) / 65535 : 1;
+            const uint8_t *src = in + in_off[item];
+            for (uint64_t b = k; b < nblk; b += step) {
+                const uint64_t pos = b * 65535;
+                const uint32_t blen = (uint32_t)(ilen - pos < 65535 ? ilen - pos : 65535);
+                uint8_t *q = o + hdr + b * (65535 + 5);
+                if (threadIdx.x == 0) {
+                    q[0] = (finish && b == nblk - 1) ? 1 : 0;
+                    q[1] = (uint8_t)blen;
+                    q[2] = (uint8_t)(blen >> 8);
+                    q[3] = (uint8_t)~blen;
+                    q[4] = (uint8_t)(~blen >> 8);
+                }
+                copy_bytes(q + 5, src + pos, blen);
+            }
+        }
+    }
+}
+
 uint64_t chunk_upper_bound(size_t n, uint64_t total_in) { return total_in / kChunk + n; }
 
 }  // namespace
@@ -1530,9 +1652,10 @@ size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int leve
     const size_t pairs = level >= 10 ? align_up((size_t)deflate_grid_bound(chunks) * kChunk * kPairs * 4, 256) : 0;
     const uint64_t stride = scratch_stride(max_item);
     return align_up(chunks * stride, 256) + align_up((chunks + 1) * 4, 256) * 2 +
-           align_up((n + 1) * 4, 256) + align_up((size_t)1024 * kTokCap * 4, 256) +
+           align_up((n + 1) * 4, 256) + align_up((size_t)1024 * kTokCap * 2, 256) +
            checksum_ws_bytes(n, total_in) + pairs +
-           align_up((size_t)1024 * kMaxBlocks * kBlkCostStride, 256) + 4096;
+           align_up((size_t)1024 * kMaxBlocks * kBlkCostStride, 256) + align_up((chunks + 1) * 8, 256) +
+           align_up((n + 1) * 4, 256) + 4096;
 }
 
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
@@ -1553,9 +1676,11 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     uint8_t *scratch = static_cast<uint8_t *>(ws_take(e, chunks * stride));
     uint32_t *chunk_size = static_cast<uint32_t *>(ws_take(e, (chunks + 1) * 4));
     uint32_t *chunk_first = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
-    uint32_t *tokbuf = static_cast<uint32_t *>(ws_take(e, (size_t)grid * kTokCap * 4));
+    uint16_t *tokbuf = static_cast<uint16_t *>(ws_take(e, (size_t)grid * kTokCap * 2));
     uint32_t *sums = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
     uint8_t *costbuf = static_cast<uint8_t *>(ws_take(e, (size_t)grid * kMaxBlocks * kBlkCostStride));
+    uint64_t *chunk_dst = static_cast<uint64_t *>(ws_take(e, (chunks + 1) * 8));
+    uint32_t *item_mode = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
     uint32_t *pairbuf = nullptr;
     if (level >= 10) {
         pairbuf = static_cast<uint32_t *>(ws_take(e, (size_t)grid * kChunk * kPairs * 4));
@@ -1564,7 +1689,7 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
             return RSX_E_NOMEM;
         }
     }
-    if (!scratch || !chunk_size || !chunk_first || !tokbuf || !sums || !costbuf) {
+    if (!scratch || !chunk_size || !chunk_first || !tokbuf || !sums || !costbuf || !chunk_dst || !item_mode) {
         e->err = "workspace exhausted";
         return RSX_E_NOMEM;
     }
@@ -1602,10 +1727,13 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
                                 total_in, max_item, sums, trusted_max);
         if (r != RSX_OK) return r;
     }
-    deflate_gather_kernel<<<(uint32_t)n, 256, 0, e->stream>>>(format, level, in_off, (uint32_t)n,
-                                                              chunk_first, scratch, stride, chunk_size,
-                                                              sums, out, out_off, out_sizes, status, in,
-                                                              flush == RSX_FLUSH_FINISH);
+    deflate_plan_kernel<<<(uint32_t)n, 256, 0, e->stream>>>(format, level, in_off, (uint32_t)n, chunk_first,
+                                                            chunk_size, sums, out, out_off, out_sizes, status,
+                                                            chunk_dst, item_mode, flush == RSX_FLUSH_FINISH);
+    const uint32_t place_grid = (uint32_t)(chunks < 65536 ? chunks : 65536);
+    deflate_place_kernel<<<place_grid, 256, 0, e->stream>>>(in_off, (uint32_t)n, chunk_first, (uint32_t)chunks,
+                                                            scratch, stride, chunk_size, chunk_dst, item_mode,
+                                                            out, out_off, in, format, flush == RSX_FLUSH_FINISH);
     RSX_HIP(e, hipGetLastError());
     return RSX_OK;
 }
