@@ -53,6 +53,9 @@ constexpr uint32_t kChunk = 256 * 1024;         // src/compress/mod.rs:699-700
 // the table does not depend on the order the lanes arrive in.  (The reference keeps hash chains,
 // matchfinder.rs:754-891: a chain is a serial walk of dependent loads, a row is read at once and
 // its tags drop nearly every candidate that is only a hash collision.)
+#ifndef RSX_SPLIT_FROM_LEVEL
+#define RSX_SPLIT_FROM_LEVEL 7
+#endif
 #ifndef RSX_STRAGGLERS
 #define RSX_STRAGGLERS 0
 #endif
@@ -67,17 +70,26 @@ static_assert(256 * 1024 + 1 < (1u << (32 - kTagBits)), "position + 1 fits above
 constexpr int kHashBits = 13;                   // 2^13 heads (the reference hashes to 15 bits, matchfinder.rs:784)
 constexpr uint32_t kNearDist = 8;               // distances 1..kNearDist are checked from registers
 constexpr uint32_t kWindow = 32768;
-constexpr uint32_t kBlockSoft = 65535 - kCT - 300;  // close the block once it holds this many bytes
+// Blocks end where the statistics of the tokens change (src/compress/mod.rs:278-416) and at
+// 64 KiB: the reference's soft limit of 300000 bytes (src/common.rs:69) lies above the chunk
+// size, and its test asks for savings that grow with the block, so that past 64 KiB it hardly
+// ever ends one; data whose kind changes every 64 KiB loses a tenth of its ratio that way.
+constexpr uint32_t kBlockSoft = 65535 - kCT - 300;   // ... and once it holds this many bytes
+constexpr uint32_t kMinBlock = 5000;            // src/common.rs:68
+constexpr uint32_t kObsPerCheck = 2048;         // src/compress/mod.rs:276
+constexpr uint32_t kObsTypes = 14;              // 8 literal classes, 2 length classes, 4 offset classes
 constexpr uint32_t kTokCap = 66 * 1024;         // 16-bit token units per block (<= bytes per block)
-// Bit output: one round of packing (two token units per lane, at most 28 bits each) plus the 16-byte
-// unit the round before left open are staged in LDS and leave it as whole 16-byte stores.
-constexpr uint32_t kStageWords = 2 * kCT * 28 / 32 + 64;
+// Bit output (emit kernel): one round of packing (two token units per lane, at most 28 bits each)
+// plus the 16-byte unit the round before left open are staged in LDS and leave it as whole
+// 16-byte stores.
+constexpr int kET = 512;                        // threads of the emit kernel
+constexpr uint32_t kStageWords = 2 * kET * 28 / 32 + 64;
+static_assert(kStageWords / 4 < kET, "one stage unit per lane");
 constexpr uint32_t kPairs = 8;                  // recorded matches per position (levels 10-12)
-constexpr uint32_t kMaxBlocks = 8;              // blocks per chunk
+constexpr uint32_t kMaxBlocks = kChunk / kMinBlock + 4;   // blocks per chunk
 constexpr uint32_t kSegment = 8192;             // positions per piece of the cost-based parse (at least)
 constexpr uint32_t kMaxCuts = kChunk / kSegment + kMaxBlocks;
-static_assert(kChunk / kBlockSoft + 2 <= kMaxBlocks, "block list");
-constexpr uint32_t kScratchPad = 256;           // chunk scratch = chunk_len + kScratchPad
+constexpr uint32_t kScratchPad = 1024;          // chunk scratch = chunk_len + kScratchPad (a stored block costs 5-6 bytes more than its data, a chunk has at most kMaxBlocks)
 // LDS copy of the input around the current batch: 32 KiB of history, the batch, and
 // the longest match behind it; slid forward kInSlide bytes at a time
 constexpr uint32_t kInSlide = 4096;
@@ -101,6 +113,7 @@ struct LevelParams {
     uint32_t max_depth, nice_len, lazy;
     uint32_t optimal;   // levels 10-12: cost-based parse over all recorded matches
     uint32_t chains;    // levels 7-12: hash chains instead of the row table
+    uint32_t split;     // block ends also follow the statistics of the tokens
 };
 
 // src/compress/mod.rs:543-602 and :624-630
@@ -114,9 +127,10 @@ __host__ inline LevelParams level_params(int level)
     LevelParams p;
     p.max_depth = depth[level];
     p.nice_len = nice[level];
-    p.lazy = level >= 5 ? 1 : 0;
+    p.lazy = level >= 8 ? 2 : level >= 5 ? 1 : 0;   // src/compress/mod.rs:624-630
     p.optimal = level >= 10 ? 1 : 0;
     p.chains = level >= 7 ? 1 : 0;
+    p.split = level >= RSX_SPLIT_FROM_LEVEL ? 1 : 0;
     return p;
 }
 
@@ -152,13 +166,33 @@ struct __align__(16) ChunkLds {
     uint8_t litlen_len[288], off_len[32];
     uint32_t scan_tmp[kCT / 64 * 2];
     // control (written by one lane between barriers)
+    uint32_t obs_new[16], obs_old[16];   // block split statistics: observations since / before the last check
+    uint32_t n_obs_old;
     uint32_t block_ntok;      // 16-bit token units in the open block
     uint32_t entry;           // chunk position of the next token start
     uint32_t block_start;     // chunk position where the open block starts
     uint32_t next_entry;      // scratch for the parse hand-over
+    uint32_t tok_base;        // token units of the chunk in front of the open block
+    uint32_t nout;            // blocks of the chunk closed so far (entries of the block table)
+    uint32_t huff_scratch[288 + 32];   // (levels 10-12: code lengths of the first pass)
+    uint32_t len_counts[2][16];
+    uint32_t huff_flag[2];           // an alphabet needs the length-limiting walk
+    uint32_t blk_end[kMaxBlocks], nblk;   // block ends found by the first pass (levels 10-12)
+    uint32_t cut[kMaxCuts], ncut;         // ends of the pieces of the cost-based parse; bit 31 = also a block end
+};
+
+// LDS of the emit kernel: one block's histograms and codes, the header scratch, the output stage
+struct __align__(16) EmitLds {
+    uint8_t len_slot[260];
+    uint32_t litlen_freq[288], off_freq[32];
+    uint32_t litlen_code[288], off_code[32];   // bit-reversed codeword
+    uint8_t litlen_len[288], off_len[32];
+    uint32_t scan_tmp[kET / 64 * 2];
+    uint32_t block_ntok;      // 16-bit token units of the block
+    uint32_t block_start;     // chunk position where the block starts
     uint64_t out_bits;        // bits written to the chunk output so far
     uint32_t stage_word0;     // output word that stage[0] stands for (a multiple of 4)
-    uint32_t stage[kStageWords];   // output words [stage_word0, ...): bits are OR-ed in, then flushed
+    alignas(16) uint32_t stage[kStageWords];   // output words [stage_word0, ...): bits are OR-ed in, then flushed
     uint32_t huff_scratch[288 + 32];
     uint32_t len_counts[2][16];
     uint32_t huff_flag[2];           // an alphabet needs the length-limiting walk
@@ -166,9 +200,8 @@ struct __align__(16) ChunkLds {
     uint8_t pre_len[20];
     uint32_t nl, no, np;             // code lengths sent per alphabet
     uint32_t body_bits;
-    unsigned long long run_mask[5];
-    uint32_t blk_end[kMaxBlocks], nblk;   // block ends found by the first pass (levels 10-12)
-    uint32_t cut[kMaxCuts], ncut;         // ends of the pieces of the cost-based parse; bit 31 = also a block end  // first lanes of the runs of equal code lengths
+    unsigned long long run_mask[5];  // first lanes of the runs of equal code lengths
+    alignas(16) uint32_t pj[640 + 160];   // node depths, then the run-length items of the header
 };
 
 // ---- bit output -------------------------------------------------------------------
@@ -178,7 +211,7 @@ constexpr uint32_t kUnitLen = 0x4000, kUnitDist = 0x8000;
 
 // Any lane: OR `nbits` (<= 57) bits of `value` into the stage at absolute bit position `pos` of
 // the chunk output.  The position must lie inside the staged window.
-__device__ inline void stage_or(ChunkLds &L, uint64_t pos, uint64_t value, uint32_t nbits)
+__device__ inline void stage_or(EmitLds &L, uint64_t pos, uint64_t value, uint32_t nbits)
 {
     if (nbits == 0) return;
     const uint32_t w = (uint32_t)(pos >> 5) - L.stage_word0, sh = (uint32_t)(pos & 31);
@@ -191,11 +224,11 @@ __device__ inline void stage_or(ChunkLds &L, uint64_t pos, uint64_t value, uint3
 // All lanes, behind a barrier that follows the ORs: the complete 16-byte units below bit
 // `upto` go to the output with plain stores, the unit that is still open moves to the front of
 // the stage and the rest of the stage is cleared.
-__device__ inline void stage_flush(ChunkLds &L, uint32_t *out_words, uint64_t upto)
+__device__ inline void stage_flush(EmitLds &L, uint32_t *out_words, uint64_t upto)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t w0 = L.stage_word0;
-    const uint32_t full = (uint32_t)(upto >> 7) - (w0 >> 2);   // (< kStageWords / 4 <= kCT)
+    const uint32_t full = (uint32_t)(upto >> 7) - (w0 >> 2);   // (< kStageWords / 4 <= kET)
     uint4 *st = reinterpret_cast<uint4 *>(L.stage);
     uint4 tail = make_uint4(0, 0, 0, 0);
 #ifndef RSX_NO_OUTSTORE
@@ -210,10 +243,10 @@ __device__ inline void stage_flush(ChunkLds &L, uint32_t *out_words, uint64_t up
 
 // All lanes: `count` bytes of the input from `src` as they are, at the byte-aligned bit
 // position L.out_bits (stored blocks).
-__device__ inline void stage_bytes(ChunkLds &L, uint32_t *out_words, const uint8_t *src, uint32_t count)
+__device__ inline void stage_bytes(EmitLds &L, uint32_t *out_words, const uint8_t *src, uint32_t count)
 {
     const uint32_t tid = threadIdx.x;
-    for (uint32_t base = 0; base < count; base += 4 * kCT) {
+    for (uint32_t base = 0; base < count; base += 4 * kET) {
         const uint64_t pos = L.out_bits;   // (bits of the rounds before included)
         const uint32_t at = base + 4 * tid;
         if (at < count) {
@@ -223,7 +256,7 @@ __device__ inline void stage_bytes(ChunkLds &L, uint32_t *out_words, const uint8
             stage_or(L, pos + 32ull * tid, v, 8 * nb);
         }
         WG_SYNC();
-        const uint32_t done = count - base < 4 * kCT ? count - base : 4 * kCT;
+        const uint32_t done = count - base < 4 * kET ? count - base : 4 * kET;
         if (tid == 0) L.out_bits = pos + 8ull * done;
         stage_flush(L, out_words, pos + 8ull * done);
     }
@@ -404,8 +437,9 @@ __device__ void huff_collective(bool on, uint32_t sym, uint32_t num_syms, uint32
 __device__ unsigned long long g_deflate_t[16];
 #define DT_MARK(k) do { if (RSX_DEV_TIMERS && threadIdx.x == 0) { unsigned long long t_ = clock64(); dt[k] += t_ - tq; tq = t_; } } while (0)
 
-// exclusive prefix sum over the workgroup (returns the total through *total)
-__device__ inline uint32_t wg_exclusive_scan(ChunkLds &L, uint32_t v, uint32_t *total)
+// exclusive prefix sum over a workgroup of kThreads lanes (returns the total through *total)
+template <int kThreads, class LS>
+__device__ inline uint32_t wg_exclusive_scan(LS &L, uint32_t v, uint32_t *total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t x = v;
@@ -417,7 +451,7 @@ __device__ inline uint32_t wg_exclusive_scan(ChunkLds &L, uint32_t v, uint32_t *
     if (lane == 63) L.scan_tmp[w] = x;
     WG_SYNC();
     uint32_t before = 0, all = 0;
-    for (int k = 0; k < kCT / 64; k++) {
+    for (int k = 0; k < kThreads / 64; k++) {
         uint32_t s = L.scan_tmp[k];
         if (k < w) before += s;
         all += s;
@@ -461,17 +495,15 @@ __device__ inline uint32_t precode_extra_bits(uint32_t sym) { return sym == 16 ?
 // All lanes: Huffman codes of the open block, the block type decision (src/compress/mod.rs:
 // 1375-1398), its header (mod.rs:1775-1883), the tokens, and a fresh block state.
 // in = chunk input, tok = this workgroup's token buffer.
-__device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint32_t block_end, bool is_final,
+__device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, bool is_final,
                             const uint16_t *tok, uint32_t *out_words)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t ntok = L.block_ntok;
     const uint32_t bstart = L.block_start;
     const uint32_t block_bytes = block_end - bstart;
-    // scratch over the parse tables, which are idle here
-    uint32_t *pj = reinterpret_cast<uint32_t *>(L.jump);               // [0, 640): node depths
+    uint32_t *pj = L.pj;                                               // [0, 640): node depths
     uint16_t *items = reinterpret_cast<uint16_t *>(pj + 640);          // <= 320 run-length items
-    static_assert(sizeof(L.jump) >= (640 + 160) * 4, "scratch for the block header");
     if (tid == 0) {
         L.litlen_freq[256] = 1;  // end of block
         L.nl = 257;
@@ -541,7 +573,7 @@ __device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint
         rle_run(mylen, run, [&](uint32_t, uint32_t) { cnt++; });
     }
     uint32_t nitems;
-    uint32_t ioff = wg_exclusive_scan(L, cnt, &nitems);
+    uint32_t ioff = wg_exclusive_scan<kET>(L, cnt, &nitems);
     if (start)
         rle_run(mylen, run, [&](uint32_t sym, uint32_t extra) {
             items[ioff++] = (uint16_t)((sym << 8) | extra);
@@ -558,26 +590,33 @@ __device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint
         ibits = L.pre_len[it >> 8] + precode_extra_bits(it >> 8);
     }
     uint32_t items_bits;
-    const uint32_t ipos = wg_exclusive_scan(L, ibits, &items_bits);
+    const uint32_t ipos = wg_exclusive_scan<kET>(L, ibits, &items_bits);
     const uint32_t np = L.np;
     const uint64_t hdr_bits = 3 + 5 + 5 + 4 + 3 * np + items_bits;
     const uint64_t body_bits = L.body_bits;
     const uint64_t pos = L.out_bits;
-    const uint64_t stored_bits = (((pos + 3 + 7) & ~7ull) - pos) + 32 + 8ull * block_bytes;
-    const bool stored = block_bytes <= 65535 && stored_bits <= hdr_bits + body_bits;
+    // as stored blocks of at most 65535 bytes: the first starts at any bit, the others on a byte
+    const uint32_t stored_pieces = block_bytes ? (block_bytes + 65534) / 65535 : 1;
+    const uint64_t stored_bits = (((pos + 3 + 7) & ~7ull) - pos) + 32 + 8ull * block_bytes + 40ull * (stored_pieces - 1);
+    const bool stored = stored_bits <= hdr_bits + body_bits;
     WG_SYNC();   // everyone has read out_bits
     if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[7], t_ - fq); fq = t_; }
+    if (RSX_DEV_TIMERS && tid == 0) { atomicAdd(&g_deflate_t[14], 1ull); if (stored) atomicAdd(&g_deflate_t[15], 1ull); }
     if (stored) {
-        // stored block (src/compress/mod.rs:1408-1448): header bits, align, LEN, NLEN, bytes
-        const uint64_t p = (pos + 3 + 7) & ~7ull;
-        if (tid == 0) {
-            stage_or(L, pos, is_final ? 1 : 0, 3);
-            stage_or(L, p, block_bytes | ((~block_bytes & 0xFFFF) << 16), 32);
-            L.out_bits = p + 32;
+        // stored blocks (src/compress/mod.rs:1408-1448): header bits, align, LEN, NLEN, bytes
+        for (uint32_t piece = 0; piece < stored_pieces; piece++) {
+            const uint32_t from = piece * 65535, plen = block_bytes - from < 65535 ? block_bytes - from : 65535;
+            const uint64_t q0 = L.out_bits, q = (q0 + 3 + 7) & ~7ull;
+            WG_SYNC();   // everyone has read out_bits
+            if (tid == 0) {
+                stage_or(L, q0, (is_final && piece + 1 == stored_pieces) ? 1 : 0, 3);
+                stage_or(L, q, plen | ((~plen & 0xFFFF) << 16), 32);
+                L.out_bits = q + 32;
+            }
+            WG_SYNC();
+            stage_flush(L, out_words, q + 32);
+            stage_bytes(L, out_words, in + bstart + from, plen);
         }
-        WG_SYNC();
-        stage_flush(L, out_words, p + 32);
-        stage_bytes(L, out_words, in + bstart, block_bytes);
     } else {
         if (tid == 0) stage_or(L, pos, (is_final ? 1 : 0) | (2 << 1) | ((nl - 257) << 3) | ((no - 1) << 8) | ((np - 4) << 13), 17);
         if (tid < np) stage_or(L, pos + 17 + 3 * tid, L.pre_len[k_precode_perm[tid]], 3);
@@ -590,12 +629,13 @@ __device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint
         stage_flush(L, out_words, at_bits);
         // Rounds of two token units per lane: code bits in registers, a prefix sum of the lanes'
         // bit counts, one OR of up to 56 bits into the stage, a flush of the complete units.
-        for (uint32_t base = 0; base < ntok; base += 2 * kCT) {
+        for (uint32_t base = 0; base < ntok; base += 2 * kET) {
             const uint32_t i0 = base + 2 * tid;
             uint64_t val = 0;
             uint32_t nb = 0;
             if (i0 < ntok) {
-                const uint32_t pair = *reinterpret_cast<const uint32_t *>(tok + i0);   // (i0 is even)
+                // (a block's units start anywhere in the chunk's token buffer: two 16-bit loads)
+                const uint32_t pair = tok[i0] | (i0 + 1 < ntok ? (uint32_t)tok[i0 + 1] << 16 : 0);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const uint32_t u = h ? pair >> 16 : pair & 0xFFFF;
@@ -619,7 +659,7 @@ __device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint
                 }
             }
             uint32_t round_bits;
-            const uint32_t off = wg_exclusive_scan(L, nb, &round_bits);
+            const uint32_t off = wg_exclusive_scan<kET>(L, nb, &round_bits);
             stage_or(L, at_bits + off, val, nb);
             WG_SYNC();
             at_bits += round_bits;
@@ -631,14 +671,6 @@ __device__ __forceinline__ void flush_block(ChunkLds &L, const uint8_t *in, uint
         }
         WG_SYNC();
         stage_flush(L, out_words, at_bits + L.litlen_len[256]);
-    }
-    WG_SYNC();
-    // reset the block state
-    for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
-    if (tid < 32) L.off_freq[tid] = 0;
-    if (tid == 0) {
-        L.block_ntok = 0;
-        L.block_start = block_end;
     }
     WG_SYNC();
 }
@@ -731,6 +763,8 @@ __device__ void record_block(ChunkLds &L, uint32_t block_end, uint8_t *blkcost)
     WG_SYNC();
     for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
     if (tid < 32) L.off_freq[tid] = 0;
+    if (tid < 16) L.obs_new[tid] = L.obs_old[tid] = 0;
+    if (tid == 16) L.n_obs_old = 0;
     if (tid == 0) {
         L.blk_end[k] = block_end;
         L.nblk = k + 1;
@@ -811,6 +845,34 @@ __device__ void optimal_parse_piece(const ChunkLds &L, const uint8_t *in, uint32
     }
 }
 
+// One entry of the block table: where the block ends in the chunk and how many token units it has.
+// Its histograms (288 literal/length + 32 offset counts, 16 bits each: a block has fewer than 65536
+// bytes) lie in a table of their own.
+constexpr uint32_t kHistStride = 320;
+
+// All lanes (match kernel): the open block ends at block_end.  Its histograms and size go to the
+// chunk's block table for the emit kernel; a fresh block starts.
+__device__ inline void close_block(ChunkLds &L, uint32_t block_end, uint2 *blk_tab, uint16_t *blk_hist)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = L.nout, units = L.block_ntok;
+    if (tid < 288) blk_hist[k * kHistStride + tid] = (uint16_t)L.litlen_freq[tid];
+    else if (tid < 320) blk_hist[k * kHistStride + tid] = (uint16_t)L.off_freq[tid - 288];
+    if (tid == 0) blk_tab[k] = make_uint2(block_end, units);
+    WG_SYNC();
+    for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
+    if (tid < 32) L.off_freq[tid] = 0;
+    if (tid < 16) L.obs_new[tid] = L.obs_old[tid] = 0;
+    if (tid == 16) L.n_obs_old = 0;
+    if (tid == 0) {
+        L.nout = k + 1;
+        L.tok_base += units;
+        L.block_ntok = 0;
+        L.block_start = block_end;
+    }
+    WG_SYNC();
+}
+
 // Copy chunk positions [from, to) into the LDS input buffer with 16-byte units
 // aligned to the global address.  LDS index of chunk position p is p - w0 + phase.
 __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, uint32_t w0,
@@ -825,24 +887,24 @@ __device__ inline void stage_input(ChunkLds &L, const uint8_t *in, uint32_t n, u
         reinterpret_cast<uint4 *>(L.inbuf)[u] = *reinterpret_cast<const uint4 *>(g + 16 * (size_t)u);
 }
 
-// Compress one chunk (<= 256 KiB) into `out_words` (zeroed, chunk_len + kScratchPad
-// bytes).  Returns the number of bytes written (uniform over the workgroup).
+// Match and parse one chunk (<= 256 KiB): token units into `tok`, one block table entry and one
+// histogram per block.  Returns the number of blocks (uniform over the workgroup).
 // mp / blkcost: per-workgroup buffers of the cost-based parse (levels 10-12 only).
 // kOptimal: levels 10-12 (cost-based parse); a compile-time switch keeps the recording and
 // replay code out of the kernel of the other levels
 template <bool kOptimal, bool kChains>
-__device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, bool last_chunk,
-                                   LevelParams lp, uint16_t *tok, uint32_t *out_words, uint32_t *mp,
-                                   uint8_t *blkcost)
+__device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, LevelParams lp, uint16_t *tok,
+                                   uint2 *blk_tab, uint16_t *blk_hist, uint32_t *mp, uint8_t *blkcost)
 {
     const int tid = threadIdx.x;
-    // reset the tables and the output stage
+    // reset the tables
     {
-        for (uint32_t i = tid; i < kStageWords; i += kCT) L.stage[i] = 0;
         for (uint32_t i = tid; i < (kChains ? (1u << kHashBits) : kRows * kWays) / 4; i += kCT)
             reinterpret_cast<uint4 *>(L.rows)[i] = make_uint4(0, 0, 0, 0);   // (the chain heads lie in front)
         for (int i = tid; i < 288; i += kCT) L.litlen_freq[i] = 0;
         if (tid < 32) L.off_freq[tid] = 0;
+        if (tid < 16) L.obs_new[tid] = L.obs_old[tid] = 0;
+        if (tid == 16) L.n_obs_old = 0;
         for (int i = tid; i < 260; i += kCT) {
             uint32_t s = 0;
             while (s + 1 < 29 && k_len_base[s + 1] <= (uint32_t)i) s++;
@@ -852,8 +914,8 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
             L.block_ntok = 0;
             L.entry = 0;
             L.block_start = 0;
-            L.out_bits = 0;
-            L.stage_word0 = 0;
+            L.tok_base = 0;
+            L.nout = 0;
             L.m_len[0] = 0;
             L.m_off[0] = 0;
             L.nblk = 0;
@@ -868,32 +930,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
     if (lp.max_depth != 0) stage_input(L, in, n, 0, phase, 0, staged);
     WG_SYNC();
 
-    if (n == 0) {
-        // an empty input is an empty final fixed-Huffman block: BFINAL=1, BTYPE=01, end-of-block (7 zero bits)
-        if (tid == 0) {
-            if (last_chunk) stage_or(L, 0, 3, 3);
-            L.out_bits = last_chunk ? 10 : 0;
-        }
-        WG_SYNC();
-    }
-
-    if (lp.max_depth == 0) {
-        // level 0: stored blocks only (src/compress/mod.rs:1400-1449)
-        for (uint32_t pos = 0; pos < n; pos += 65535) {
-            const uint32_t blen = n - pos < 65535 ? n - pos : 65535;
-            const uint64_t q0 = L.out_bits, q = (q0 + 3 + 7) & ~7ull;
-            WG_SYNC();   // everyone has read out_bits
-            if (tid == 0) {
-                stage_or(L, q0, (last_chunk && pos + blen >= n) ? 1 : 0, 3);
-                stage_or(L, q, blen | ((~blen & 0xFFFF) << 16), 32);
-                L.out_bits = q + 32;
-            }
-            WG_SYNC();
-            stage_flush(L, out_words, q + 32);
-            stage_bytes(L, out_words, in + pos, blen);
-        }
-        n = 0;  // nothing left for the matcher
-    }
+    if (lp.max_depth == 0) n = 0;   // level 0: stored blocks only, written by the emit kernel
 
     unsigned long long dt[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tq = RSX_DEV_TIMERS ? clock64() : 0;
@@ -1198,7 +1235,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         const uint32_t entry = L.entry;
         const uint32_t kEnd = kCT + 1;
         // next(s): slot of the following token start, tokens emitted by a start at s
-        uint32_t my_next = kEnd, ntoks = 0, t0 = 0, t1 = 0;
+        uint32_t my_next = kEnd, ntoks = 0, t0 = 0, t1 = 0, t2 = 0;
         {
             const uint32_t s = tid;
             if (s < lim && !(b0 == 0 && s == 0)) {
@@ -1206,11 +1243,21 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 if (len >= 3) {
                     uint32_t len1 = (s + 1 < nslots) ? L.m_len[s + 1] : 0;
                     if (lp.lazy && !replay && len < lp.nice_len && len1 > len) {
-                        // compress/mod.rs:1290-1336 (one lazy step): literal, then the longer match
+                        // compress/mod.rs:1290-1336: a literal, then the longer match; with two lazy
+                        // steps (levels 8, 9) two literals if the position after that is longer still
+                        // (at the end of a batch, where that position is not searched yet, one step)
+                        const uint32_t len2 = (lp.lazy >= 2 && s + 2 < nslots) ? L.m_len[s + 2] : 0;
                         t0 = byte_at(pos);
-                        t1 = tok_match(len1, (uint32_t)L.m_off[s + 1] + 1);
-                        ntoks = 2;
-                        my_next = s + 1 + len1;
+                        if (len2 > len1) {
+                            t1 = byte_at(pos + 1);
+                            t2 = tok_match(len2, (uint32_t)L.m_off[s + 2] + 1);
+                            ntoks = 3;
+                            my_next = s + 2 + len2;
+                        } else {
+                            t1 = tok_match(len1, (uint32_t)L.m_off[s + 1] + 1);
+                            ntoks = 2;
+                            my_next = s + 1 + len1;
+                        }
                     } else {
                         t0 = tok_match(len, (uint32_t)L.m_off[s] + 1);
                         ntoks = 1;
@@ -1296,35 +1343,40 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 ustage[at] = (uint16_t)t;
             }
         };
-        const uint32_t my_units = live ? units_of(t0) + (ntoks == 2 ? units_of(t1) : 0) : 0;
+        // histograms (compress/mod.rs:1306-1351)
+        auto count_token = [&](uint32_t t) {
+            if (t >> 31) {
+                const uint32_t len = (t & 0xFF) + 3, os = offset_slot(((t >> 8) & 0x7FFF) + 1);
+                atomicAdd(&L.litlen_freq[257 + L.len_slot[len]], 1u);
+                atomicAdd(&L.off_freq[os], 1u);
+            } else {
+                atomicAdd(&L.litlen_freq[t], 1u);
+            }
+        };
+        const uint32_t u0 = units_of(t0), u1 = ntoks >= 2 ? units_of(t1) : 0, u2 = ntoks >= 3 ? units_of(t2) : 0;
+        const uint32_t my_units = live ? u0 + u1 + u2 : 0;
         uint32_t cnt = my_units + (livex ? units_of(x_t0) : 0);
         uint32_t total;
-        uint32_t at = wg_exclusive_scan(L, cnt, &total);
-        const uint32_t tbase = L.block_ntok, ta = tbase & 7;
+        uint32_t at = wg_exclusive_scan<kCT>(L, cnt, &total);
+        const uint32_t tbase = L.tok_base + L.block_ntok, ta = tbase & 7;   // units of the chunk so far
         if ((uint32_t)tid < ta) ustage[tid] = L.tok_tail[tid];
         if (live) {
             put_units(ta + at, t0);
-            if (ntoks == 2) put_units(ta + at + units_of(t0), t1);
-            // histograms (compress/mod.rs:1306-1351)
-            uint32_t tt = ntoks == 2 ? t1 : t0;
-            if (ntoks == 2 || !(t0 & 0x80000000u)) atomicAdd(&L.litlen_freq[t0 & 0xFF], 1u);
-            if (tt & 0x80000000u) {
-                uint32_t len = (tt & 0xFF) + 3, dist = ((tt >> 8) & 0x7FFF) + 1;
-                atomicAdd(&L.litlen_freq[257 + L.len_slot[len]], 1u);
-                atomicAdd(&L.off_freq[offset_slot(dist)], 1u);
+            count_token(t0);
+            if (ntoks >= 2) {
+                put_units(ta + at + u0, t1);
+                count_token(t1);
+            }
+            if (ntoks >= 3) {
+                put_units(ta + at + u0 + u1, t2);
+                count_token(t2);
             }
             // the marked slot whose successor leaves the decided range hands over
             if (my_next >= lim) L.next_entry = base_pos + my_next;
         }
         if (livex) {
             put_units(ta + at + my_units, x_t0);
-            if (x_t0 & 0x80000000u) {
-                uint32_t len = (x_t0 & 0xFF) + 3, dist = ((x_t0 >> 8) & 0x7FFF) + 1;
-                atomicAdd(&L.litlen_freq[257 + L.len_slot[len]], 1u);
-                atomicAdd(&L.off_freq[offset_slot(dist)], 1u);
-            } else {
-                atomicAdd(&L.litlen_freq[x_t0 & 0xFF], 1u);
-            }
+            count_token(x_t0);
             L.next_entry = base_pos + x_next;
         }
         WG_SYNC();
@@ -1338,7 +1390,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         }
         if (tid == 0) {
             if (total) L.entry = L.next_entry;
-            L.block_ntok = tbase + total;
+            L.block_ntok = tbase - L.tok_base + total;
             // carry the last position's match to slot 0 of the next batch
             L.m_len[0] = L.m_len[kCT];
             L.m_off[0] = L.m_off[kCT];
@@ -1349,7 +1401,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
         const uint32_t covered = L.entry;   // every byte below is inside an emitted token
         if (replay) {
             if (tail) {
-                flush_block(L, in, n_eff, n_eff == n && last_chunk, tok, out_words);
+                close_block(L, n_eff, blk_tab, blk_hist);
                 b0 = n_eff;
                 blk++;
                 n_eff = blk < L.nblk ? L.blk_end[blk] : n;
@@ -1357,10 +1409,51 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
                 b0 += kCT;
             }
         } else {
-            if (tail || covered - L.block_start >= kBlockSoft || L.block_ntok + 3 * kCT + 4 > kTokCap) {
+            // should_end_block (compress/mod.rs:387-415), looked at once per batch: with enough new
+            // observations in a block of at least kMinBlock bytes that does not end the chunk,
+            // the block ends if coding the new observations with their own statistics instead
+            // of the block's saves more than a sixteenth of a bit per byte of the block
+            // (do_end_block_check, :359-384); otherwise they join the block's.
+            // The observation classes (:303-346: literals by their top three bits, lengths below
+            // and from 8, offsets up to 256, 4096 and 32768) are sums over the block's symbol
+            // histograms, and the number of observations is the number of token units.
+            bool split = false;
+            {
+                const uint32_t n_old = L.n_obs_old, n_new = L.block_ntok - n_old;
+                const uint32_t block_len = covered - L.block_start;
+                if (lp.split && !tail && n_new >= kObsPerCheck && n - covered > kMinBlock && block_len >= kMinBlock) {
+                    if (tid < kObsTypes) {
+                        const uint32_t *f = tid < 10 ? L.litlen_freq : L.off_freq;
+                        const uint32_t lo = tid < 8 ? 32 * tid : tid == 8 ? 257 : tid == 9 ? 262 : tid == 10 ? 0 : tid == 11 ? 16 : 24;
+                        const uint32_t hi = tid < 8 ? lo + 32 : tid == 8 ? 262 : tid == 9 ? 286 : tid == 10 ? 16 : tid == 11 ? 24 : tid == 12 ? 30 : 24;
+                        uint32_t sum = 0;
+                        for (uint32_t k = lo; k < hi; k++) sum += f[k];
+                        L.obs_new[tid] = sum - L.obs_old[tid];
+                    }
+                    WG_SYNC();
+                    if (n_old) {
+                        const uint32_t lg_old = 31 - __clz(n_old), lg_new = 31 - __clz(n_new);
+                        uint32_t old_bits = 0, new_bits = 0;
+#pragma unroll
+                        for (uint32_t i = 0; i < kObsTypes; i++) {
+                            const uint32_t nw = L.obs_new[i];
+                            const uint32_t lo = 31 - __clz(L.obs_old[i] + 1), ln = 31 - __clz(nw + 1);
+                            old_bits += nw * (lg_old > lo ? lg_old - lo : 0);
+                            new_bits += nw * (lg_new > ln ? lg_new - ln : 0);
+                        }
+                        split = (int32_t)(old_bits - new_bits) > (int32_t)(block_len / 16);
+                    }
+                    if (!split) {
+                        WG_SYNC();   // everyone has read the statistics
+                        if (tid < kObsTypes) L.obs_old[tid] += L.obs_new[tid];
+                        if (tid == 16) L.n_obs_old = n_old + n_new;
+                    }
+                }
+            }
+            if (tail || split || covered - L.block_start >= kBlockSoft || L.block_ntok + 3 * kCT + 4 > kTokCap) {
                 const uint32_t block_end = tail ? n : covered;
                 if (analysis) record_block(L, block_end, blkcost);
-                else flush_block(L, in, block_end, tail && last_chunk, tok, out_words);
+                else close_block(L, block_end, blk_tab, blk_hist);
             } else if (analysis) {
                 // the parse is cut into pieces where the first pass has a token boundary, so
                 // the cheapest path of a piece is never dearer than the first pass's tokens
@@ -1378,21 +1471,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, b
     if (RSX_DEV_TIMERS && tid == 0)
         for (int k = 0; k < 6; k++) atomicAdd(&g_deflate_t[k], dt[k]);
 
-    // chunk trailer: sync flush between chunks (src/compress/mod.rs:662-681)
-    {
-        const uint64_t p0 = L.out_bits;
-        const uint64_t p = last_chunk ? (p0 + 7) & ~7ull : ((p0 + 3 + 7) & ~7ull) + 32;
-        WG_SYNC();   // everyone has read out_bits
-        if (tid == 0) {
-            if (!last_chunk) stage_or(L, p - 32, 0xFFFF0000u, 32);   // empty stored block header, byte aligned
-            L.out_bits = p;
-        }
-        WG_SYNC();
-        stage_flush(L, out_words, p);
-        // the unit that is still open (zero bits behind the last byte)
-        if (tid == 0) reinterpret_cast<uint4 *>(out_words + L.stage_word0)[0] = reinterpret_cast<uint4 *>(L.stage)[0];
-    }
-    return (uint32_t)(L.out_bits >> 3);
+    WG_SYNC();
+    return L.nout;
+
 }
 
 // ---- chunk bookkeeping ---------------------------------------------------------------
@@ -1427,42 +1508,158 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__rest
     if (threadIdx.x == 0) chunk_first[n] = carry;
 }
 
-// Persistent workgroups: workgroup g compresses chunks g, g + gridDim.x, ...
+// Which item a chunk belongs to, where it lies in the input, whether it ends the item's stream.
+struct ChunkPlace {
+    uint64_t in_at;    // offset of the chunk's first byte in `in`
+    uint32_t len;      // its length
+    bool ends_item;    // no chunk of the item follows
+};
+
+__device__ inline ChunkPlace place_chunk(const uint64_t *in_off, uint32_t n, const uint32_t *chunk_first, uint32_t ch)
+{
+    uint32_t lo = 0, hi = n;   // item with chunk_first[item] <= ch < chunk_first[item+1]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (chunk_first[mid] <= ch) lo = mid; else hi = mid;
+    }
+    const uint32_t item = lo, k = ch - chunk_first[item];
+    const uint64_t ib = in_off[item], len = in_off[item + 1] - ib;
+    const uint64_t cb = (uint64_t)k * kChunk;
+    ChunkPlace c;
+    c.in_at = ib + cb;
+    c.len = (uint32_t)(len - cb < kChunk ? len - cb : kChunk);
+    c.ends_item = cb + c.len >= len;
+    return c;
+}
+
+// Match kernel.  Persistent workgroups: workgroup g takes chunks g, g + gridDim.x, ...; per chunk
+// the token units go to tokbuf + chunk * tok_stride, the block table to blk_tab / blk_hist +
+// chunk * kMaxBlocks entries, the number of blocks to chunk_blocks.
 template <bool kOptimal, bool kChains>
 __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
-    uint8_t *__restrict__ scratch, uint64_t scratch_stride, uint16_t *__restrict__ tokbuf,
-    uint32_t *__restrict__ chunk_size, uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf,
-    int finish)
+    uint64_t scratch_stride, uint16_t *__restrict__ tokbuf, uint64_t tok_stride,
+    uint2 *__restrict__ blk_tab, uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ chunk_blocks,
+    uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf)
 {
     __shared__ ChunkLds L;
     uint32_t *mp = pairbuf ? pairbuf + (size_t)blockIdx.x * kChunk * kPairs : nullptr;
     uint8_t *blkcost = costbuf + (size_t)blockIdx.x * kMaxBlocks * kBlkCostStride;
     const uint32_t total_chunks = chunk_first[n];
-    uint16_t *tok = tokbuf + (size_t)blockIdx.x * kTokCap;
     for (uint32_t ch = blockIdx.x; ch < total_chunks && ch < chunk_slots; ch += gridDim.x) {
-        uint32_t lo = 0, hi = n;   // item with chunk_first[item] <= ch < chunk_first[item+1]
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (chunk_first[mid] <= ch) lo = mid; else hi = mid;
-        }
-        const uint32_t item = lo, k = ch - chunk_first[item];
-        const uint64_t ib = in_off[item], len = in_off[item + 1] - ib;
-        const uint64_t cb = (uint64_t)k * kChunk;
-        const uint32_t clen = (uint32_t)(len - cb < kChunk ? len - cb : kChunk);
-        // FlushMode::Sync leaves the item's stream open: every chunk ends byte aligned, none is final
-        const bool last = finish && cb + clen >= len;
-        uint32_t *outw = reinterpret_cast<uint32_t *>(scratch + (size_t)ch * scratch_stride);
-        if ((uint64_t)clen + kScratchPad > scratch_stride) {
+        const ChunkPlace c = place_chunk(in_off, n, chunk_first, ch);
+        // the caller understated the longest item: the chunk has no room in the token buffer or
+        // in the chunk scratch (the emit kernel makes the item fall back or fail)
+        if ((uint64_t)c.len + kScratchPad > scratch_stride) continue;
+        const uint32_t nb = compress_chunk<kOptimal, kChains>(L, in + c.in_at, c.len, lp, tokbuf + (size_t)ch * tok_stride,
+                                                              blk_tab + (size_t)ch * kMaxBlocks,
+                                                              blk_hist + (size_t)ch * kMaxBlocks * kHistStride, mp, blkcost);
+        if (threadIdx.x == 0) chunk_blocks[ch] = nb;
+        WG_SYNC();
+    }
+}
+
+// Emit kernel: one workgroup per chunk.  Per block: Huffman codes from the histogram, the block
+// type decision, the header and the token bits (flush_block); level 0 and empty chunks are written
+// here as well; then the sync flush marker between chunks (src/compress/mod.rs:662-681).  With
+// little LDS and 512 lanes several chunks share a CU, so the serial parts of the code construction
+// of one hide behind the others.
+#ifndef RSX_EMIT_OCC
+#define RSX_EMIT_OCC 8   // waves per SIMD the emit kernel is compiled for (four workgroups per CU)
+#endif
+__global__ __launch_bounds__(kET, RSX_EMIT_OCC) void deflate_emit_kernel(
+    const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
+    const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, int stored_only,
+    uint8_t *__restrict__ scratch, uint64_t scratch_stride, const uint16_t *__restrict__ tokbuf, uint64_t tok_stride,
+    const uint2 *__restrict__ blk_tab, const uint16_t *__restrict__ blk_hist,
+    const uint32_t *__restrict__ chunk_blocks, uint32_t *__restrict__ chunk_size, int finish)
+{
+    __shared__ EmitLds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total_chunks = chunk_first[n];
+    for (uint32_t ch = blockIdx.x; ch < total_chunks && ch < chunk_slots; ch += gridDim.x) {
+        const ChunkPlace c = place_chunk(in_off, n, chunk_first, ch);
+        if ((uint64_t)c.len + kScratchPad > scratch_stride) {
             // the caller understated the longest item: never write past the chunk's slot; the
             // size makes the item fall back to stored blocks or report InsufficientSpace (uniform)
-            if (threadIdx.x == 0) chunk_size[ch] = 0x7FFFFFFFu;
+            if (tid == 0) chunk_size[ch] = 0x7FFFFFFFu;
             continue;
         }
-        uint32_t sz;
-        sz = compress_chunk<kOptimal, kChains>(L, in + ib + cb, clen, last, lp, tok, outw, mp, blkcost);
-        if (threadIdx.x == 0) chunk_size[ch] = sz;
+        // FlushMode::Sync leaves the item's stream open: every chunk ends byte aligned, none is final
+        const bool last_chunk = finish && c.ends_item;
+        const uint8_t *src = in + c.in_at;
+        uint32_t *out_words = reinterpret_cast<uint32_t *>(scratch + (size_t)ch * scratch_stride);
+        for (uint32_t i = tid; i < kStageWords; i += kET) L.stage[i] = 0;
+        for (int i = tid; i < 260; i += kET) {
+            uint32_t s = 0;
+            while (s + 1 < 29 && k_len_base[s + 1] <= (uint32_t)i) s++;
+            L.len_slot[i] = (uint8_t)s;
+        }
+        if (tid == 0) {
+            L.out_bits = 0;
+            L.stage_word0 = 0;
+        }
+        WG_SYNC();
+        if (c.len == 0) {
+            // an empty input is an empty final fixed-Huffman block: BFINAL=1, BTYPE=01, end-of-block (7 zero bits)
+            if (tid == 0) {
+                if (last_chunk) stage_or(L, 0, 3, 3);
+                L.out_bits = last_chunk ? 10 : 0;
+            }
+            WG_SYNC();
+        } else if (stored_only) {
+            // level 0: stored blocks only (src/compress/mod.rs:1400-1449)
+            for (uint32_t pos = 0; pos < c.len; pos += 65535) {
+                const uint32_t blen = c.len - pos < 65535 ? c.len - pos : 65535;
+                const uint64_t q0 = L.out_bits, q = (q0 + 3 + 7) & ~7ull;
+                WG_SYNC();   // everyone has read out_bits
+                if (tid == 0) {
+                    stage_or(L, q0, (last_chunk && pos + blen >= c.len) ? 1 : 0, 3);
+                    stage_or(L, q, blen | ((~blen & 0xFFFF) << 16), 32);
+                    L.out_bits = q + 32;
+                }
+                WG_SYNC();
+                stage_flush(L, out_words, q + 32);
+                stage_bytes(L, out_words, src + pos, blen);
+            }
+        } else {
+            const uint32_t nb = chunk_blocks[ch];
+            const uint2 *tab = blk_tab + (size_t)ch * kMaxBlocks;
+            const uint16_t *hist = blk_hist + (size_t)ch * kMaxBlocks * kHistStride;
+            const uint16_t *tok = tokbuf + (size_t)ch * tok_stride;
+            uint32_t start = 0, unit0 = 0;
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint2 e = tab[k];   // (block end, token units)
+                if (tid < 288) L.litlen_freq[tid] = hist[k * kHistStride + tid];
+                else if (tid < 320) L.off_freq[tid - 288] = hist[k * kHistStride + tid];
+                if (tid == 0) {
+                    L.block_ntok = e.y;
+                    L.block_start = start;
+                }
+                WG_SYNC();
+                flush_block(L, src, e.x, last_chunk && k + 1 == nb, tok + unit0, out_words);
+                start = e.x;
+                unit0 += e.y;
+            }
+        }
+        // chunk trailer: sync flush between chunks (src/compress/mod.rs:662-681)
+        {
+            const uint64_t p0 = L.out_bits;
+            const uint64_t p = last_chunk ? (p0 + 7) & ~7ull : ((p0 + 3 + 7) & ~7ull) + 32;
+            WG_SYNC();   // everyone has read out_bits
+            if (tid == 0) {
+                if (!last_chunk) stage_or(L, p - 32, 0xFFFF0000u, 32);   // empty stored block header, byte aligned
+                L.out_bits = p;
+            }
+            WG_SYNC();
+            stage_flush(L, out_words, p);
+            // the unit that is still open (zero bits behind the last byte)
+            if (tid == 0) {
+                reinterpret_cast<uint4 *>(out_words + L.stage_word0)[0] = reinterpret_cast<uint4 *>(L.stage)[0];
+                chunk_size[ch] = (uint32_t)(p >> 3);
+            }
+        }
         WG_SYNC();
     }
 }
@@ -1639,6 +1836,14 @@ uint64_t chunk_upper_bound(size_t n, uint64_t total_in) { return total_in / kChu
 // upper bound on the workgroups deflate_launch starts
 static uint32_t deflate_grid_bound(uint64_t chunks) { return (uint32_t)(chunks < 1024 ? chunks : 1024); }
 
+// token units per chunk in the token buffer: at most one per byte, and the last 16-byte piece of a
+// batch may end up to 7 units behind them
+static uint64_t tok_stride_units(uint64_t max_item)
+{
+    const uint64_t longest = max_item < kChunk ? max_item : kChunk;
+    return align_up(longest + 64, 8);
+}
+
 // bytes of scratch per chunk: no chunk is longer than the longest item
 static uint64_t scratch_stride(uint64_t max_item)
 {
@@ -1652,7 +1857,8 @@ size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int leve
     const size_t pairs = level >= 10 ? align_up((size_t)deflate_grid_bound(chunks) * kChunk * kPairs * 4, 256) : 0;
     const uint64_t stride = scratch_stride(max_item);
     return align_up(chunks * stride, 256) + align_up((chunks + 1) * 4, 256) * 2 +
-           align_up((n + 1) * 4, 256) + align_up((size_t)1024 * kTokCap * 2, 256) +
+           align_up((n + 1) * 4, 256) + align_up(chunks * tok_stride_units(max_item) * 2, 256) + align_up(chunks * kMaxBlocks * sizeof(uint2), 256) +
+           align_up(chunks * kMaxBlocks * kHistStride * 2, 256) + align_up((chunks + 1) * 4, 256) +
            checksum_ws_bytes(n, total_in) + pairs +
            align_up((size_t)1024 * kMaxBlocks * kBlkCostStride, 256) + align_up((chunks + 1) * 8, 256) +
            align_up((n + 1) * 4, 256) + 4096;
@@ -1676,7 +1882,11 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     uint8_t *scratch = static_cast<uint8_t *>(ws_take(e, chunks * stride));
     uint32_t *chunk_size = static_cast<uint32_t *>(ws_take(e, (chunks + 1) * 4));
     uint32_t *chunk_first = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
-    uint16_t *tokbuf = static_cast<uint16_t *>(ws_take(e, (size_t)grid * kTokCap * 2));
+    const uint64_t tok_units = tok_stride_units(max_item);
+    uint16_t *tokbuf = static_cast<uint16_t *>(ws_take(e, chunks * tok_units * 2));
+    uint2 *blk_tab = static_cast<uint2 *>(ws_take(e, chunks * kMaxBlocks * sizeof(uint2)));
+    uint16_t *blk_hist = static_cast<uint16_t *>(ws_take(e, chunks * kMaxBlocks * kHistStride * 2));
+    uint32_t *chunk_blocks = static_cast<uint32_t *>(ws_take(e, (chunks + 1) * 4));
     uint32_t *sums = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
     uint8_t *costbuf = static_cast<uint8_t *>(ws_take(e, (size_t)grid * kMaxBlocks * kBlkCostStride));
     uint64_t *chunk_dst = static_cast<uint64_t *>(ws_take(e, (chunks + 1) * 8));
@@ -1689,22 +1899,30 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
             return RSX_E_NOMEM;
         }
     }
-    if (!scratch || !chunk_size || !chunk_first || !tokbuf || !sums || !costbuf || !chunk_dst || !item_mode) {
+    if (!scratch || !chunk_size || !chunk_first || !tokbuf || !blk_tab || !blk_hist || !chunk_blocks || !sums ||
+        !costbuf || !chunk_dst || !item_mode) {
         e->err = "workspace exhausted";
         return RSX_E_NOMEM;
     }
     LevelParams lp = level_params(level);
     chunk_scan_kernel<<<1, 1024, 0, e->stream>>>(in_off, (uint32_t)n, chunk_first);
     (void)hipEventRecord(e->ev_begin, e->stream);
-#define RSX_LAUNCH_CHUNKS(OPT, CH)                                                                        \
-    deflate_chunks_kernel<OPT, CH><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,     \
-                                                                (uint32_t)chunks, lp, scratch, stride, tokbuf, \
-                                                                chunk_size, pairbuf, costbuf,            \
-                                                                flush == RSX_FLUSH_FINISH)
-    if (lp.optimal) RSX_LAUNCH_CHUNKS(true, true);
+#define RSX_LAUNCH_CHUNKS(OPT, CH)                                                                          \
+    deflate_chunks_kernel<OPT, CH><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,       \
+                                                                (uint32_t)chunks, lp, stride, tokbuf, tok_units, \
+                                                                blk_tab, blk_hist, chunk_blocks, pairbuf, costbuf)
+    if (level == 0) { /* stored blocks only: nothing to match */ }
+    else if (lp.optimal) RSX_LAUNCH_CHUNKS(true, true);
     else if (lp.chains) RSX_LAUNCH_CHUNKS(false, true);
     else RSX_LAUNCH_CHUNKS(false, false);
 #undef RSX_LAUNCH_CHUNKS
+    {
+        const uint32_t emit_grid = (uint32_t)(chunks < 65536 ? chunks : 65536);
+        deflate_emit_kernel<<<emit_grid, kET, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first, (uint32_t)chunks,
+                                                               level == 0, scratch, stride, tokbuf, tok_units, blk_tab,
+                                                               blk_hist, chunk_blocks, chunk_size,
+                                                               flush == RSX_FLUSH_FINISH);
+    }
     (void)hipEventRecord(e->ev_end, e->stream);
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
@@ -1713,11 +1931,12 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
         RSX_HIP(e, hipStreamSynchronize(e->stream));
         RSX_HIP(e, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_deflate_t), sizeof t));
         fprintf(stderr, "[deflate] cycles/chunk: slide %.0f insert %.0f search %.0f parse %.0f emit %.0f flush %.0f (codes %.0f header %.0f); "
-                        "wave 0: near %.0f rows %.0f cycles, %.1f near rounds and %.1f row rounds per batch, per lane %.2f candidates, %.2f compared in full\n",
+                        "wave 0: near %.0f rows %.0f cycles, %.1f near rounds and %.1f row rounds per batch, per lane %.2f candidates, %.2f compared in full; %.2f blocks per chunk, %.3f of them stored\n",
                 t[0] / (double)chunks, t[1] / (double)chunks, t[2] / (double)chunks, t[3] / (double)chunks,
                 t[4] / (double)chunks, t[5] / (double)chunks, t[6] / (double)chunks, t[7] / (double)chunks,
                 t[8] / (double)chunks, t[9] / (double)chunks, t[10] / (double)chunks / 256, t[11] / (double)chunks / 256,
-                t[12] / (double)chunks / 256 / 64, t[13] / (double)chunks / 256 / 64);
+                t[12] / (double)chunks / 256 / 64, t[13] / (double)chunks / 256 / 64, t[14] / (double)chunks,
+                t[15] / (double)(t[14] ? t[14] : 1));
         unsigned long long z[16] = {0};
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_deflate_t), z, sizeof z));
     }
