@@ -1,6 +1,8 @@
-"""Copies the newest summaries of a tools/profile_round.sh + tools/pmc_pass.sh run from gpurun_out/ into
-profiles/<round>/ and rewrites bench_traffic.json from the two HBM counter passes.
-usage: python tools/collect_profiles.py r01"""
+"""Condenses a tools/profile_round.sh run (gpurun_out/prof/) into profiles/<round>/: the kernel statistics as
+they are, one small CSV of every counter per kernel (mean per dispatch), the bench lines, and bench_traffic.json
+(HBM bytes per batch of the engine's own kernels = 2 x FETCH_SIZE + WRITE_SIZE, both in KiB: on gfx950 FETCH_SIZE
+counts half of the bytes of 16-byte-per-lane reads).
+usage: python tools/collect_profiles.py r02"""
 import collections
 import csv
 import glob
@@ -9,57 +11,59 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 base, dest = "gpurun_out/prof", "profiles/" + rnd
 os.makedirs(dest, exist_ok=True)
+DOMINANT = {"decompress": ("inflate_decode_kernel", "inflate_expand_kernel"), "compress": ("deflate_chunks_kernel", "deflate_emit_kernel")}
+OURS = ("inflate_", "deflate_", "checksum_", "verify_trailer", "chunk_scan", "seg_scan")
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
 
 
 def newest(pattern):
     return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1]
 
 
-def kernel_stats(op):
+rows_out = []
+traffic = {}
+for op in ("decompress", "compress"):
     f = newest("%s/%s_stats/**/*kernel_stats.csv" % (base, op))
-    for r in list(csv.DictReader(open(f)))[:3]:
-        print(op, r["Name"][:56], r["Calls"], "%.3f ms" % (float(r["AverageNs"]) / 1e6))
     shutil.copy(f, "%s/%s_kernel_stats.csv" % (dest, op))
-
-
-def counter_kb(op, kind, name, kernel):
-    f = newest("%s/%s_%s/**/*counter_collection.csv" % (base, op, kind))
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
-    shutil.copy(f, "%s/%s_pmc_%s.csv" % (dest, op, name))
-    print(op, name, "%.0f KB per launch over %d launches" % (sum(vals) / len(vals), len(vals)))
-    return sum(vals) / len(vals) * 1024
-
-
-total = {}
-for op, kernel in (("decompress", "inflate_kernel"), ("compress", "deflate_chunks_kernel")):
-    kernel_stats(op)
-    fetch = counter_kb(op, "fetch", "fetch_size", kernel)
-    write = counter_kb(op, "write", "write_size", kernel)
-    total[op] = int(2 * fetch + write)   # gfx950: FETCH_SIZE counts half of 16-byte-per-lane reads
-    print(op, "HBM bytes per launch", total[op])
     shutil.copy("%s/%s_bench_line.json" % (base, op), "%s/%s_bench_line.json" % (dest, op))
-    for line in open("%s/%s_bench_line.json" % (dest, op)):
-        if line.startswith("{"):
-            d = json.loads(line)
-            print(op, "bench %.1f GiB/s, kernel %.2f ms" % (d["value"], d["roofline"]["kernel_ms"]))
+    for r in list(csv.DictReader(open(f)))[:6]:
+        print(op, short(r["Name"])[:48], r["Calls"], "%.3f ms" % (float(r["AverageNs"]) / 1e6))
+    per = collections.defaultdict(lambda: [0.0, set()])
+    for tag in ("fetch", "write", "sq1", "sq2"):
+        fs = glob.glob("%s/%s_%s/**/*counter_collection.csv" % (base, op, tag), recursive=True)
+        for cf in fs:
+            for r in csv.DictReader(open(cf)):
+                k = short(r["Kernel_Name"])
+                if not k.startswith(OURS):
+                    continue
+                e = per[(k, r["Counter_Name"])]
+                e[0] += float(r["Counter_Value"])
+                e[1].add(r["Dispatch_Id"])
+    tot = dom = 0.0
+    for (k, c), (v, d) in sorted(per.items()):
+        rows_out.append((op, k, c, v / len(d), len(d)))
+        b = 2 * 1024 * v / len(d) if c == "FETCH_SIZE" else 1024 * v / len(d) if c == "WRITE_SIZE" else 0.0
+        tot += b
+        if k.startswith(DOMINANT[op]):
+            dom += b
+    traffic[op] = (dom, tot)
+with open("%s/counters_per_kernel.csv" % dest, "w") as f:
+    w = csv.writer(f)
+    w.writerow(["bench", "kernel", "counter", "mean_per_dispatch", "dispatches"])
+    for r in rows_out:
+        w.writerow([r[0], r[1], r[2], "%.6g" % r[3], r[4]])
+# a batch = one dispatch of every kernel, except those dispatched more than once per batch (none today)
 j = json.load(open("bench_traffic.json"))
-j["decompress:4096x1024KiB:gzip:6"] = total["decompress"]
-j["compress:4096x1024KiB:mixed:6"] = total["compress"]
+j["decompress:4096x1024KiB:gzip:6"] = {"dominant_kernels": int(traffic["decompress"][0]), "all_kernels": int(traffic["decompress"][1])}
+j["compress:4096x1024KiB:mixed:6"] = {"dominant_kernels": int(traffic["compress"][0]), "all_kernels": int(traffic["compress"][1])}
 with open("bench_traffic.json", "w") as f:
     json.dump(j, f, indent=1)
     f.write("\n")
-for tag in ("sq_inflate", "sq_deflate"):
-    fs = glob.glob("gpurun_out/pmc/%s/**/*counter_collection.csv" % tag, recursive=True)
-    if not fs:
-        continue
-    f = sorted(fs, key=os.path.getmtime)[-1]
-    shutil.copy(f, "%s/%s_counters.csv" % (dest, tag))
-    acc, n = collections.defaultdict(float), collections.defaultdict(int)
-    for r in csv.DictReader(open(f)):
-        if "inflate_kernel" in r["Kernel_Name"] or "deflate_chunks" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"])
-            n[r["Counter_Name"]] += 1
-    print(tag, {k: "%.4g" % (v / n[k]) for k, v in acc.items()})
+print({k: "%.3f GB dominant, %.3f GB all" % (v[0] / 1e9, v[1] / 1e9) for k, v in traffic.items()})
