@@ -97,11 +97,19 @@ def test_level_ordering_and_ratio_vs_oracle(eng):
     d = b"a" * 10000
     sizes = {lvl: len(eng.batch_compress([d], 0, lvl)[0][0]) for lvl in (0, 1, 6, 12)}
     assert sizes[0] > sizes[1] >= sizes[12]
-    t = [corpus.text(1 << 20, s) for s in range(4)] + [corpus.mixed(1 << 20, 7)]
-    comp, _ = eng.batch_compress(t, 0, 6)
-    for d, c in zip(t, comp):
-        ref = o.compress(d, 6)
-        assert len(c) <= 1.06 * len(ref), (len(c), len(ref))
+    # sizes against the oracle at the same level: within 2 % on text, mixed and JSON-like data at levels 6
+    # and 9, except JSON at level 6, where the row table of levels 1-6 offers twelve candidates per 4-byte
+    # string against the 35 steps of the reference's chain (8 % larger; level 9 walks chains: 2 % smaller)
+    sets = {"text": [corpus.text(1 << 20, s) for s in range(2)], "mixed": [corpus.mixed(1 << 20, 7)],
+            "json": [corpus.json_like(1 << 20, 21)]}
+    for level in (6, 9):
+        for kind, datas in sets.items():
+            comp, st = eng.batch_compress(datas, 0, level)
+            assert list(st) == [0] * len(datas)
+            got = sum(len(c) for c in comp)
+            ref = sum(len(o.compress(d, level)) for d in datas)
+            limit = 1.09 if (kind, level) == ("json", 6) else 1.02
+            assert got <= limit * ref, (kind, level, got, ref)
 
 
 def test_cost_based_levels(eng):
