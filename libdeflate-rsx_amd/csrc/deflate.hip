@@ -56,9 +56,6 @@ constexpr uint32_t kChunk = 256 * 1024;         // src/compress/mod.rs:699-700
 #ifndef RSX_SPLIT_FROM_LEVEL
 #define RSX_SPLIT_FROM_LEVEL 7
 #endif
-#ifndef RSX_STRAGGLERS
-#define RSX_STRAGGLERS 0
-#endif
 constexpr int kRowBits = 11;
 constexpr uint32_t kRows = 1u << kRowBits;
 constexpr uint32_t kWays = 12;
@@ -79,11 +76,12 @@ constexpr uint32_t kMinBlock = 5000;            // src/common.rs:68
 constexpr uint32_t kObsPerCheck = 2048;         // src/compress/mod.rs:276
 constexpr uint32_t kObsTypes = 14;              // 8 literal classes, 2 length classes, 4 offset classes
 constexpr uint32_t kTokCap = 66 * 1024;         // 16-bit token units per block (<= bytes per block)
-// Bit output (emit kernel): one round of packing (two token units per lane, at most 28 bits each)
+// Bit output (emit kernel): one round of packing (four token units per lane, at most 28 bits each)
 // plus the 16-byte unit the round before left open are staged in LDS and leave it as whole
 // 16-byte stores.
 constexpr int kET = 512;                        // threads of the emit kernel
-constexpr uint32_t kStageWords = 2 * kET * 28 / 32 + 64;
+constexpr uint32_t kUnitsPerLane = 4;            // token units a lane packs per round
+constexpr uint32_t kStageWords = kUnitsPerLane * kET * 28 / 32 + 64;
 static_assert(kStageWords / 4 < kET, "one stage unit per lane");
 constexpr uint32_t kPairs = 8;                  // recorded matches per position (levels 10-12)
 constexpr uint32_t kMaxBlocks = kChunk / kMinBlock + 4;   // blocks per chunk
@@ -627,40 +625,49 @@ __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, b
         WG_SYNC();
         uint64_t at_bits = pos + hdr_bits;
         stage_flush(L, out_words, at_bits);
-        // Rounds of two token units per lane: code bits in registers, a prefix sum of the lanes'
-        // bit counts, one OR of up to 56 bits into the stage, a flush of the complete units.
-        for (uint32_t base = 0; base < ntok; base += 2 * kET) {
-            const uint32_t i0 = base + 2 * tid;
-            uint64_t val = 0;
-            uint32_t nb = 0;
-            if (i0 < ntok) {
-                // (a block's units start anywhere in the chunk's token buffer: two 16-bit loads)
-                const uint32_t pair = tok[i0] | (i0 + 1 < ntok ? (uint32_t)tok[i0 + 1] << 16 : 0);
+        // Rounds of four token units per lane: code bits in registers, a prefix sum of the lanes'
+        // bit counts, two ORs of up to 56 bits into the stage, a flush of the complete units.
+        // The units of the next round are loaded before this round's barriers.
+        auto load_units = [&](uint32_t i0, uint32_t (&u)[kUnitsPerLane]) {
+            // (a block's units start anywhere in the chunk's token buffer: 16-bit loads)
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t u = h ? pair >> 16 : pair & 0xFFFF;
-                    if (i0 + h < ntok) {
-                        uint32_t code, len;
-                        if (u & kUnitDist) {
-                            const uint32_t dist = (u & 0x7FFF) + 1, os = offset_slot(dist), l2 = L.off_len[os];
-                            code = L.off_code[os] | ((dist - k_off_base[os]) << l2);
-                            len = l2 + k_off_extra[os];
-                        } else if (u & kUnitLen) {
-                            const uint32_t ml = (u & 0xFF) + 3, ls = L.len_slot[ml], l1 = L.litlen_len[257 + ls];
-                            code = L.litlen_code[257 + ls] | ((ml - k_len_base[ls]) << l1);
-                            len = l1 + k_len_extra[ls];
-                        } else {
-                            code = L.litlen_code[u];
-                            len = L.litlen_len[u];
-                        }
-                        val |= (uint64_t)code << nb;
-                        nb += len;
+            for (uint32_t h = 0; h < kUnitsPerLane; h++) u[h] = i0 + h < ntok ? tok[i0 + h] : 0;
+        };
+        uint32_t next_u[kUnitsPerLane];
+        load_units(kUnitsPerLane * tid, next_u);
+        for (uint32_t base = 0; base < ntok; base += kUnitsPerLane * kET) {
+            const uint32_t i0 = base + kUnitsPerLane * tid;
+            uint32_t un[kUnitsPerLane];
+#pragma unroll
+            for (uint32_t h = 0; h < kUnitsPerLane; h++) un[h] = next_u[h];
+            if (base + kUnitsPerLane * kET < ntok) load_units(i0 + kUnitsPerLane * kET, next_u);
+            uint64_t val[2] = {0, 0};
+            uint32_t nb[2] = {0, 0};
+#pragma unroll
+            for (uint32_t h = 0; h < kUnitsPerLane; h++) {
+                const uint32_t u = un[h];
+                if (i0 + h < ntok) {
+                    uint32_t code, len;
+                    if (u & kUnitDist) {
+                        const uint32_t dist = (u & 0x7FFF) + 1, os = offset_slot(dist), l2 = L.off_len[os];
+                        code = L.off_code[os] | ((dist - k_off_base[os]) << l2);
+                        len = l2 + k_off_extra[os];
+                    } else if (u & kUnitLen) {
+                        const uint32_t ml = (u & 0xFF) + 3, ls = L.len_slot[ml], l1 = L.litlen_len[257 + ls];
+                        code = L.litlen_code[257 + ls] | ((ml - k_len_base[ls]) << l1);
+                        len = l1 + k_len_extra[ls];
+                    } else {
+                        code = L.litlen_code[u];
+                        len = L.litlen_len[u];
                     }
+                    val[h >> 1] |= (uint64_t)code << nb[h >> 1];
+                    nb[h >> 1] += len;
                 }
             }
             uint32_t round_bits;
-            const uint32_t off = wg_exclusive_scan<kET>(L, nb, &round_bits);
-            stage_or(L, at_bits + off, val, nb);
+            const uint32_t off = wg_exclusive_scan<kET>(L, nb[0] + nb[1], &round_bits);
+            stage_or(L, at_bits + off, val[0], nb[0]);
+            stage_or(L, at_bits + off + nb[0], val[1], nb[1]);
             WG_SYNC();
             at_bits += round_bits;
             stage_flush(L, out_words, at_bits);
@@ -1159,28 +1166,36 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
                 // tag is distance << kTagBits; rotated right by kTagBits it is the distance, and
                 // with another tag a number far above any distance.  key = distance, ~0 = none.
                 const uint32_t mine = ((p + 1) << kTagBits) | tag;
-                uint32_t key[kWays];
+                // keys: distance - 1 as 16 bits, two to a register, 0xFFFF = none
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                u16x2 key[kWays / 2];
 #pragma unroll
-                for (uint32_t k = 0; k < kWays; k++) {
-                    const uint32_t t = mine - e[k];
-                    const uint32_t d = __builtin_amdgcn_alignbit(t, t, kTagBits);
-                    key[k] = d - 1 < max_dist ? d : ~0u;
+                for (uint32_t k = 0; k < kWays; k += 2) {
+                    uint32_t k16[2];
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++) {
+                        const uint32_t t = mine - e[k + h];
+                        const uint32_t d = __builtin_amdgcn_alignbit(t, t, kTagBits);
+                        k16[h] = d - 1 < max_dist ? d - 1 : 0xFFFFu;
+                    }
+                    key[k / 2] = __builtin_bit_cast(u16x2, k16[0] | (k16[1] << 16));
                 }
                 uint32_t depth = 0;
                 // the byte a candidate must match to be longer than the best so far
                 uint32_t next_byte = best_len ? L.inbuf[src_at + best_len] : 0;
+                // Nearest first: the smallest key not yet taken.  Keys minus (last taken + 1), modulo
+                // 2^16, keep the order of the keys that are left and push the taken ones above them.
+                uint32_t taken = 0;   // last taken key + 1
                 while (depth < lp.max_depth && best_len < stop_len) {
-                    uint32_t v = key[0];
+                    const u16x2 base2 = __builtin_bit_cast(u16x2, taken * 0x10001u);
+                    u16x2 m = key[0] - base2;
 #pragma unroll
-                    for (uint32_t k = 1; k < kWays; k++) v = key[k] < v ? key[k] : v;
-                    if (v == ~0u) break;
-                    // a wave does not go on for a handful of lanes: their remaining (farther)
-                    // candidates are dropped (the lanes of a wave are fixed positions, so this
-                    // depends on the data alone)
-                    if (depth >= 2 && __popcll(__ballot(true)) < RSX_STRAGGLERS) break;
-#pragma unroll
-                    for (uint32_t k = 0; k < kWays; k++) key[k] = key[k] == v ? ~0u : key[k];
-                    const uint32_t d0 = v;
+                    for (uint32_t k = 1; k < kWays / 2; k++) m = __builtin_elementwise_min(m, (u16x2)(key[k] - base2));
+                    const uint32_t mm = __builtin_bit_cast(uint32_t, m);
+                    const uint32_t r = (mm & 0xFFFF) < (mm >> 16) ? (mm & 0xFFFF) : (mm >> 16);
+                    if (r + taken >= 32768) break;   // what is left is taken or none
+                    const uint32_t d0 = r + taken + 1;
+                    taken = d0;
                     depth++;
                     it_row++;
                     if (best_len && L.inbuf[src_at - d0 + best_len] != next_byte) continue;

@@ -215,3 +215,19 @@ def test_one_large_buffer_in_each_container(eng, fmt):
     assert (r, used) == (o.SUCCESS, len(c)) and back == data
     back, st = eng.batch_decompress([c], [len(data)], fmt)
     assert list(st) == [0] and back[0] == data
+
+
+@pytest.mark.parametrize("level", [1, 6, 9, 12])
+def test_output_does_not_depend_on_timing(eng, level):
+    """The same input gives the same bytes: alone, repeated inside a large batch that fills every CU, and
+    in a second call (the match finder's table is filled by atomic max, not in arrival order)."""
+    base = [corpus.text(700000, 61), corpus.mixed(600000, 62), corpus.json_like(300000, 63)]
+    alone, st = eng.batch_compress(base, 0, level)
+    assert list(st) == [0] * len(base)
+    crowd = base * 40 if level < 9 else base * 6
+    many, st = eng.batch_compress(crowd, 0, level)
+    assert list(st) == [0] * len(crowd)
+    for i, c in enumerate(many):
+        assert c == alone[i % len(base)]
+    again, _ = eng.batch_compress(base, 0, level)
+    assert again == alone
