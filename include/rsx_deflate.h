@@ -128,6 +128,22 @@ int rsx_batch_decompress(rsx_engine *e, int format, const uint8_t *in, const uin
                          int32_t *status);
 
 /*
+ * gzip files with more than one member (pigz, concatenated .gz files).  The
+ * reference decodes the first member of its input and reports the bytes it
+ * consumed (src/decompress/mod.rs:1144-1240, the `(result, in_consumed,
+ * out_produced)` triple); a caller reaches the following members by calling
+ * again on the rest.  This entry point is that loop for a whole batch: every
+ * round decodes the next member of every item that has one, appending to the
+ * item's slot; out_sizes[i] = bytes of all members together.  Zero bytes behind
+ * the last member are padding; anything else that is not a member makes the
+ * item RSX_BAD_DATA; a member that fails gives the item that member's status.
+ * Each member's CRC-32 and ISIZE are verified.
+ */
+int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_t *in_off, size_t n,
+                                 uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
+                                 int32_t *status);
+
+/*
  * crc32 / adler32 (src/crc32/mod.rs:332, src/adler32/mod.rs:115) over every
  * item of a batch: values[i] = f(init, item i), init = 0 for CRC-32 and 1 for
  * Adler-32 when starting a new checksum.  Host pointers.

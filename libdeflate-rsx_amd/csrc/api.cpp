@@ -431,6 +431,109 @@ int rsx_batch_decompress(rsx_engine *e, int format, const uint8_t *in, const uin
                          nullptr);
 }
 
+int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_t *in_off, size_t n,
+                                 uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
+                                 int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (n == 0) return RSX_OK;
+    if (!in_off || !out_off || !out_sizes || !status) return bad(e, "null pointer");
+    BatchShape si, so;
+    if (!shape_of(in_off, n, &si)) return bad(e, "in_off not monotonic");
+    if (!shape_of(out_off, n, &so)) return bad(e, "out_off not monotonic");
+    if ((!in && si.total) || (!out && so.total)) return bad(e, "null pointer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    const size_t arr = align_up((n + 1) * sizeof(uint64_t), 256);
+    const size_t need = inflate_ws_bytes(n, si.total, so.total, e->inflate_split) + align_up(si.total + 64, 256) +
+                        align_up(so.total + 64, 256) + 8 * arr + 4096;
+    int r = ws_reserve(e, need);
+    if (r != RSX_OK) return r;
+    uint8_t *d_in = static_cast<uint8_t *>(ws_take(e, si.total + 64));
+    uint8_t *d_out = static_cast<uint8_t *>(ws_take(e, so.total + 64));
+    uint64_t *d_lo = static_cast<uint64_t *>(ws_take(e, arr)), *d_hi = static_cast<uint64_t *>(ws_take(e, arr));
+    uint64_t *d_olo = static_cast<uint64_t *>(ws_take(e, arr)), *d_ohi = static_cast<uint64_t *>(ws_take(e, arr));
+    uint64_t *d_used = static_cast<uint64_t *>(ws_take(e, arr)), *d_sizes = static_cast<uint64_t *>(ws_take(e, arr));
+    uint64_t *d_base = static_cast<uint64_t *>(ws_take(e, 256));
+    int32_t *d_status = static_cast<int32_t *>(ws_take(e, arr));
+    if (!d_in || !d_out || !d_lo || !d_hi || !d_olo || !d_ohi || !d_used || !d_sizes || !d_base || !d_status) {
+        e->err = "workspace carve failed";
+        return RSX_E_NOMEM;
+    }
+    const size_t mark = e->ws_used;   // what the rounds carve lies behind this
+    const uint8_t *src = in + in_off[0];
+    if (si.total) RSX_HIP(e, hipMemcpyAsync(d_in, src, si.total, hipMemcpyHostToDevice, e->stream));
+    RSX_HIP(e, hipMemsetAsync(d_base, 0, sizeof(uint64_t), e->stream));
+
+    // per item: where its next member starts and where its next output byte goes (relative to the staged copies)
+    std::vector<uint64_t> cur_in(n), cur_out(n), h(4 * n), h_used(n), h_sizes(n);
+    std::vector<int32_t> h_status(n);
+    std::vector<size_t> active(n), next;
+    for (size_t i = 0; i < n; i++) {
+        cur_in[i] = in_off[i] - in_off[0];
+        cur_out[i] = out_off[i] - out_off[0];
+        out_sizes[i] = 0;
+        status[i] = RSX_SUCCESS;
+        active[i] = i;
+    }
+    while (!active.empty()) {
+        const size_t m = active.size();
+        uint64_t max_out = 0;
+        for (size_t k = 0; k < m; k++) {
+            const size_t i = active[k];
+            h[k] = cur_in[i];
+            h[m + k] = in_off[i + 1] - in_off[0];
+            h[2 * m + k] = cur_out[i];
+            h[3 * m + k] = out_off[i + 1] - out_off[0];
+            if (h[3 * m + k] - h[2 * m + k] > max_out) max_out = h[3 * m + k] - h[2 * m + k];
+        }
+        RSX_HIP(e, hipMemcpyAsync(d_lo, h.data(), m * 8, hipMemcpyHostToDevice, e->stream));
+        RSX_HIP(e, hipMemcpyAsync(d_hi, h.data() + m, m * 8, hipMemcpyHostToDevice, e->stream));
+        RSX_HIP(e, hipMemcpyAsync(d_olo, h.data() + 2 * m, m * 8, hipMemcpyHostToDevice, e->stream));
+        RSX_HIP(e, hipMemcpyAsync(d_ohi, h.data() + 3 * m, m * 8, hipMemcpyHostToDevice, e->stream));
+        e->ws_used = mark;
+        const InflateSlices sl{d_hi, d_ohi, d_base, d_used};
+        r = inflate_launch(e, RSX_FORMAT_GZIP, d_in, d_lo, m, si.total, so.total, max_out, d_out, d_olo, d_sizes,
+                           d_status, e->inflate_split, &sl);
+        if (r != RSX_OK) return r;
+        RSX_HIP(e, hipMemcpyAsync(h_sizes.data(), d_sizes, m * 8, hipMemcpyDeviceToHost, e->stream));
+        RSX_HIP(e, hipMemcpyAsync(h_used.data(), d_used, m * 8, hipMemcpyDeviceToHost, e->stream));
+        RSX_HIP(e, hipMemcpyAsync(h_status.data(), d_status, m * 4, hipMemcpyDeviceToHost, e->stream));
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+        next.clear();
+        for (size_t k = 0; k < m; k++) {
+            const size_t i = active[k];
+            const uint64_t end = in_off[i + 1] - in_off[0];
+            if (h_status[k] != RSX_SUCCESS || h_used[k] == 0 || h_used[k] > end - cur_in[i] ||
+                h_sizes[k] > (out_off[i + 1] - out_off[0]) - cur_out[i]) {
+                status[i] = h_status[k] != RSX_SUCCESS ? h_status[k] : RSX_BAD_DATA;
+                out_sizes[i] = 0;
+                continue;
+            }
+            out_sizes[i] += h_sizes[k];
+            cur_out[i] += h_sizes[k];
+            cur_in[i] += h_used[k];
+            // what follows the member: nothing, zero padding, or another member
+            bool zeros = true;
+            for (uint64_t q = cur_in[i]; q < end && zeros; q++) zeros = src[q] == 0;
+            if (zeros) continue;
+            if (end - cur_in[i] >= 18 && src[cur_in[i]] == 0x1F && src[cur_in[i] + 1] == 0x8B) {
+                next.push_back(i);
+            } else {
+                status[i] = RSX_BAD_DATA;
+                out_sizes[i] = 0;
+            }
+        }
+        active.swap(next);
+    }
+    for (size_t i = 0; i < n; i++)
+        if (status[i] == RSX_SUCCESS && out_sizes[i])
+            RSX_HIP(e, hipMemcpyAsync(out + out_off[i], d_out + (out_off[i] - out_off[0]), out_sizes[i],
+                                      hipMemcpyDeviceToHost, e->stream));
+    RSX_HIP(e, hipStreamSynchronize(e->stream));
+    return RSX_OK;
+}
+
 int rsx_batch_checksum(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
                        const uint64_t *in_off, size_t n, uint32_t *values)
 {

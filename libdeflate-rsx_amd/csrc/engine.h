@@ -93,9 +93,19 @@ int inflate_static_scratch(rsx_engine *e);
 // otherwise the one-kernel decoder alone (small workspace)
 size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool split);
 // total_out / max_out: sum and maximum of the output slot sizes
+// Items that are not the slices of two prefix arrays (all device pointers): item i is
+// in[in_off[i], in_hi[i]) -> out[out_off[i], out_hi[i]); *in_base and total_in bound the bytes of
+// `in` the kernels may touch; in_used (may be null, zlib / gzip only) receives the bytes of the item
+// its stream took, header and trailer included, 0 for a failed item.
+struct InflateSlices {
+    const uint64_t *in_hi, *out_hi, *in_base;
+    uint64_t *in_used;
+};
+// slices == nullptr: the usual layout, item i = [in_off[i], in_off[i + 1]) -> [out_off[i], out_off[i + 1])
 int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off, size_t n,
                    uint64_t total_in, uint64_t total_out, uint64_t max_out, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split);
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split,
+                   const InflateSlices *slices = nullptr);
 
 // deflate.hip
 size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int level);

@@ -48,6 +48,22 @@
 
 namespace {
 
+// -DRSX_SPLIT_TIMERS=1: phase timers of the two kernels (development aid), summed over all streams:
+// 0 stage 1 header 2 warm-up 3 first scan 4 later passes 5 round tail 6 rounds 7 passes
+// 8 expand: records+scan 9 walk 10 copy 11 flush 12 groups 13 stored
+#ifndef RSX_SPLIT_TIMERS
+#define RSX_SPLIT_TIMERS 0
+#endif
+#if RSX_SPLIT_TIMERS
+static __device__ unsigned long long g_split_t[16];
+#define SPLIT_T_ADD(k, v) atomicAdd(&g_split_t[k], (unsigned long long)(v))
+#define SPLIT_T_NOW() clock64()
+#else
+#define SPLIT_T_ADD(k, v) do { } while (0)
+#define SPLIT_T_NOW() 0ull
+#endif
+
+
 constexpr int kT = 256;                       // threads per stream
 constexpr int kRingBits = 14;
 constexpr uint32_t kRing = 1u << kRingBits;   // LDS mirror of the newest output bytes
@@ -629,8 +645,10 @@ __device__ __noinline__ void parse_block_header(LS &L, const StreamCtx &c, int64
 template <class LS>
 __device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_bit0)
 {
+    unsigned long long th0 = SPLIT_T_NOW();
     if (threadIdx.x == 0) parse_block_header(L, c, win_bit0);
     WAVE_SYNC();
+    if (RSX_SPLIT_TIMERS && threadIdx.x == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(13, t - th0); th0 = t; }
     const uint32_t plan = L.hdr.plan;   // (uniform)
     if (plan == 0) return;
     if (plan == 1) {
@@ -646,6 +664,7 @@ __device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_
     ok = ok && build_decode_table_wave(L.tab, 0, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits,
                                        15, L.litlen_tablebits, L.hdr.sorted_syms, nullptr, L.hdr.len_counts,
                                        L.hdr.offsets);
+    if (RSX_SPLIT_TIMERS && threadIdx.x == 0) SPLIT_T_ADD(14, SPLIT_T_NOW() - th0);
     if (threadIdx.x == 0) {
         if (!ok) {
             L.status = RSX_BAD_DATA;
@@ -1268,7 +1287,8 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
-    unsigned long long *__restrict__ stats, int only_status)
+    unsigned long long *__restrict__ stats, int only_status, const uint64_t *__restrict__ in_hi,
+    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p)
 {
     unsigned long long tS = 0, tH = 0, tD = 0, tC = 0, tF = 0, t0 = 0, nRounds = 0;
 #define STAT_BEGIN() do { if (STATS) t0 = clock64(); } while (0)
@@ -1280,10 +1300,12 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     if (only_status && status[item] != only_status) return;
     const int tid = threadIdx.x;
 
-    const uint64_t ib = in_off[item], ie = in_off[item + 1];
-    const uint64_t ob = out_off[item], oe = out_off[item + 1];
+    // item i is in[in_off[i], in_hi[i]) -> out[out_off[i], out_hi[i]); in_hi = in_off + 1 and
+    // out_hi = out_off + 1 for the usual prefix arrays
+    const uint64_t ib = in_off[item], ie = in_hi[item];
+    const uint64_t ob = out_off[item], oe = out_hi[item];
     StreamCtx c;
-    c.in_alloc = in + in_off[0];   // the batch's bytes are in[in_off[0] .. in_off[0] + total_in)
+    c.in_alloc = in + *in_base_p;   // the batch's bytes are in[base .. base + total_in)
     c.in_alloc_len = total_in;
     c.out = out + ob;
     c.out_cap = oe - ob;
@@ -1472,21 +1494,6 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
 // length - 3) or kNoTok (a length still waiting for its distance, a subtable hop, the end of
 // the block).  A row per step, not per token, keeps the lanes of a wave on the same row: every
 // store is one contiguous 256 bytes.  Rounds are listed in a per-stream array of RoundRec.
-
-// -DRSX_SPLIT_TIMERS=1: phase timers of the two kernels (development aid), summed over all streams:
-// 0 stage 1 header 2 warm-up 3 first scan 4 later passes 5 round tail 6 rounds 7 passes
-// 8 expand: records+scan 9 walk 10 copy 11 flush 12 groups 13 stored
-#ifndef RSX_SPLIT_TIMERS
-#define RSX_SPLIT_TIMERS 0
-#endif
-#if RSX_SPLIT_TIMERS
-static __device__ unsigned long long g_split_t[16];
-#define SPLIT_T_ADD(k, v) atomicAdd(&g_split_t[k], (unsigned long long)(v))
-#define SPLIT_T_NOW() clock64()
-#else
-#define SPLIT_T_ADD(k, v) do { } while (0)
-#define SPLIT_T_NOW() 0ull
-#endif
 
 constexpr int32_t kStatusPending = -2;    // decoded into tokens, not expanded yet
 constexpr int32_t kStatusFallback = -3;   // left to inflate_kernel
@@ -1716,15 +1723,16 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
 #endif
 __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
-    uint64_t total_in, int32_t *__restrict__ status, uint64_t *__restrict__ body_end, SplitLayout lay)
+    uint64_t total_in, int32_t *__restrict__ status, uint64_t *__restrict__ body_end, SplitLayout lay,
+    const uint64_t *__restrict__ in_hi, const uint64_t *__restrict__ in_base_p)
 {
     __shared__ DecodeLds L;
     const uint32_t item = blockIdx.x;
     if (item >= n) return;
     const int tid = threadIdx.x;
-    const uint64_t ib = in_off[item], ie = in_off[item + 1];
+    const uint64_t ib = in_off[item], ie = in_hi[item];
     StreamCtx c;
-    const uint64_t in_base = in_off[0];
+    const uint64_t in_base = *in_base_p;
     c.in_alloc = in + in_base;
     c.in_alloc_len = total_in;
     c.out = nullptr;
@@ -1863,15 +1871,16 @@ static_assert(kLaneBytesStop + 258 <= kXGroupOut && kXGroupOut <= kRoundOut, "on
 __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
-    int32_t *__restrict__ status, SplitLayout lay)
+    int32_t *__restrict__ status, SplitLayout lay, const uint64_t *__restrict__ in_hi,
+    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p)
 {
     __shared__ ExpandLds L;
     const uint32_t item = blockIdx.x;
     if (item >= n) return;
     if (status[item] != kStatusPending) return;   // (uniform)
     const int tid = threadIdx.x;
-    const uint64_t ib = in_off[item], ie = in_off[item + 1];
-    const uint64_t ob = out_off[item], oe = out_off[item + 1];
+    const uint64_t ib = in_off[item], ie = in_hi[item];
+    const uint64_t ob = out_off[item], oe = out_hi[item];
     StreamCtx c;
     c.in_alloc = in;
     c.in_alloc_len = 0;
@@ -1882,7 +1891,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
     c.body = in + ib + ci.hdr;
     c.body_len = (ie - ib) - ci.hdr - ci.trailer;
-    const uint64_t in_base = in_off[0];
+    const uint64_t in_base = *in_base_p;
     const uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, item) * kT;
     const RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
     const uint32_t cap = (uint32_t)c.out_cap;
@@ -2033,10 +2042,14 @@ __global__ void verify_trailer_kernel(int format, const uint8_t *__restrict__ in
                                       const uint64_t *__restrict__ in_off, uint32_t n,
                                       const uint64_t *__restrict__ body_end,
                                       const uint32_t *__restrict__ sums,
-                                      uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status)
+                                      uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status,
+                                      uint64_t *__restrict__ in_used)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || status[i] != RSX_SUCCESS) return;
+    if (i >= n) return;
+    // bytes of the item the member took, header and trailer included (0 for a failed item)
+    if (in_used) in_used[i] = status[i] == RSX_SUCCESS ? body_end[i] + (format == RSX_FORMAT_ZLIB ? 4 : 8) : 0;
+    if (status[i] != RSX_SUCCESS) return;
     const uint8_t *t = in + in_off[i] + body_end[i];
     bool ok;
     if (format == RSX_FORMAT_ZLIB) {
@@ -2050,6 +2063,7 @@ __global__ void verify_trailer_kernel(int format, const uint8_t *__restrict__ in
     if (!ok) {
         status[i] = RSX_BAD_DATA;
         out_sizes[i] = 0;
+        if (in_used) in_used[i] = 0;
     }
 }
 
@@ -2087,9 +2101,14 @@ size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool sp
 
 int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t *in_off, size_t n,
                    uint64_t total_in, uint64_t total_out, uint64_t max_out, uint8_t *out,
-                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split)
+                   const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split,
+                   const InflateSlices *slices)
 {
     if (n == 0) return RSX_OK;
+    const uint64_t *in_hi = slices ? slices->in_hi : in_off + 1;
+    const uint64_t *out_hi = slices ? slices->out_hi : out_off + 1;
+    const uint64_t *in_base_p = slices ? slices->in_base : in_off;
+    uint64_t *in_used = slices ? slices->in_used : nullptr;
     // (output positions are 32-bit in the kernels, and a round adds up to 16 KiB before it is checked)
     if (n > 0x7FFFFFFFull || max_out >= (1ull << 32) - (1ull << 16)) {
         e->err = "batch too large (output slots must be < 4 GiB - 64 KiB, n < 2^31)";
@@ -2109,18 +2128,20 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     const uint32_t grid = (uint32_t)n;
     (void)hipEventRecord(e->ev_begin, e->stream);
     if (split) {
-        inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay);
+        inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
+                                                          in_hi, in_base_p);
         inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
-                                                          lay);
+                                                          lay, in_hi, out_hi, in_base_p);
         // whatever the two left (damaged streams, slots that are too small, streams that need more
         // token space than the workspace has) is decoded again by the one-kernel decoder
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                          status, body_end, nullptr, kStatusFallback);
+                                                          status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
+                                                          in_base_p);
     } else if (e->inflate_stats) {
         unsigned long long *d_stats = nullptr;   // (development aid: allocates and synchronises)
         RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
         inflate_kernel<true><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                         status, body_end, d_stats, 0);
+                                                         status, body_end, d_stats, 0, in_hi, out_hi, in_base_p);
         (void)hipEventRecord(e->ev_end, e->stream);
         std::vector<unsigned long long> h(n * 12);
         RSX_HIP(e, hipMemcpy(h.data(), d_stats, h.size() * 8, hipMemcpyDeviceToHost));
@@ -2138,7 +2159,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                 (double)sum[11] / n);
     } else {
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                          status, body_end, nullptr, 0);
+                                                          status, body_end, nullptr, 0, in_hi, out_hi, in_base_p);
     }
     if (split || !e->inflate_stats) (void)hipEventRecord(e->ev_end, e->stream);
 #if RSX_SPLIT_TIMERS
@@ -2149,8 +2170,8 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_split_t), z, sizeof z));
         const double d = (double)n;
         fprintf(stderr, "[rsx split] per stream: decode rounds %.1f passes %.1f cycles: stage %.0f header %.0f warm %.0f scan %.0f "
-                        "passes %.0f tail %.0f | expand groups %.1f cycles: records %.0f walk %.0f copy %.0f flush %.0f\n",
-                t[6] / d, t[7] / d, t[0] / d, t[1] / d, t[2] / d, t[3] / d, t[4] / d, t[5] / d, t[12] / d, t[8] / d, t[9] / d,
+                        "passes %.0f tail %.0f (header: read %.0f, tables %.0f) | expand groups %.1f cycles: records %.0f walk %.0f copy %.0f flush %.0f\n",
+                t[6] / d, t[7] / d, t[0] / d, t[1] / d, t[2] / d, t[3] / d, t[4] / d, t[5] / d, t[13] / d, t[14] / d, t[12] / d, t[8] / d, t[9] / d,
                 t[10] / d, t[11] / d);
     }
 #endif
@@ -2164,7 +2185,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         int r = checksum_launch(e, kind, init, out, out_off, out_sizes, n, total_out, max_out, sums, false);
         if (r != RSX_OK) return r;
         verify_trailer_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, e->stream>>>(
-            format, in, in_off, (uint32_t)n, body_end, sums, out_sizes, status);
+            format, in, in_off, (uint32_t)n, body_end, sums, out_sizes, status, in_used);
         RSX_HIP(e, hipGetLastError());
     }
     return RSX_OK;

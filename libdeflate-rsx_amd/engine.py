@@ -28,6 +28,7 @@ SYMBOLS = [
     ("rsx_batch_compress", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_compress_flush", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_decompress", C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    ("rsx_batch_decompress_members", C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_checksum", C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, C.c_size_t, _P]),
     ("rsx_crc32", C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("rsx_adler32", C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -174,6 +175,22 @@ class Engine:
         self._check(self._lib.rsx_batch_decompress(self._h, fmt, _np_ptr(flat), in_off.ctypes.data, n,
                                                    out.ctypes.data, out_off.ctypes.data,
                                                    sizes.ctypes.data, status.ctypes.data))
+        res = [out[int(out_off[i]):int(out_off[i]) + int(sizes[i])].tobytes() if status[i] == 0 else None
+               for i in range(n)]
+        return res, status[:n]
+
+    def batch_decompress_members(self, items, max_out_sizes):
+        """gzip items that may hold several members -> (list of bytes-or-None, status ndarray)"""
+        n = len(items)
+        flat, in_off = self._flatten(items)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.asarray(max_out_sizes, dtype=np.uint64), out=out_off[1:])
+        out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+        sizes = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        self._check(self._lib.rsx_batch_decompress_members(self._h, _np_ptr(flat), in_off.ctypes.data, n,
+                                                           out.ctypes.data, out_off.ctypes.data,
+                                                           sizes.ctypes.data, status.ctypes.data))
         res = [out[int(out_off[i]):int(out_off[i]) + int(sizes[i])].tobytes() if status[i] == 0 else None
                for i in range(n)]
         return res, status[:n]

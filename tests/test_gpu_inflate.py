@@ -233,3 +233,36 @@ def test_long_codewords_use_subtables(eng):
             streams.append(c)
             caps.append(len(d))
     check_against_oracle(eng, streams, caps, 0)
+
+
+def test_gzip_files_with_several_members(rsx, eng):
+    """rsx_batch_decompress_members: every member of every item, appended in its slot; checked against
+    Python's gzip module (which reads multi-member files) and, member by member, against the oracle."""
+    import gzip
+    parts = [corpus.text(300000, 71), corpus.mixed(200000, 72), b"", corpus.json_like(70000, 73), b"x"]
+    gz = [gzip.compress(p, 6, mtime=0) for p in parts]
+    for p, g in zip(parts, gz):
+        assert o.decompress(g, len(p), o.FMT_GZIP)[0] == o.SUCCESS
+    items = [gz[0],                                   # one member
+             gz[0] + gz[1],                           # two
+             b"".join(gz),                            # five, with an empty one in the middle
+             gz[3] + bytes(512),                      # zero padding behind the member
+             gz[1] + b"trailing text that is no member",
+             gz[0] + gz[1][:-9],                      # second member cut short
+             gz[4] * 40,                              # forty one-byte members
+             gz[0] + gz[1][:100] + b"\xff" * 50 + gz[1][150:]]   # second member damaged
+    want = [parts[0], parts[0] + parts[1], b"".join(parts), parts[3], None, None, b"x" * 40, None]
+    caps = [700000] * len(items)
+    got, st = eng.batch_decompress_members(items, caps)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, i
+        assert (st[i] == 0) == (w is not None), (i, st[i])
+        if w is not None:
+            assert gzip.decompress(items[i]) == w
+    assert st[4] == rsx.BAD_DATA
+    # a slot that holds the first member but not the second
+    got, st = eng.batch_decompress_members([gz[0] + gz[1]], [len(parts[0]) + 10])
+    assert got == [None] and st[0] == rsx.INSUFFICIENT_SPACE
+    # the single-member entry point stops behind the first member, like the reference
+    got, st = eng.batch_decompress([gz[0] + gz[1]], [700000], rsx.FORMAT_GZIP)
+    assert got == [parts[0]] and st[0] == 0
