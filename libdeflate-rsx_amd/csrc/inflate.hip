@@ -45,22 +45,34 @@
 #ifndef RSX_DBG
 #define RSX_DBG 0   // development checks
 #endif
+#ifndef RSX_TWO_BARRIERS
+#define RSX_TWO_BARRIERS 0   // 1: the copy phase's rounds separate their reads from their writes (for comparison)
+#endif
 
 namespace {
 
 // -DRSX_SPLIT_TIMERS=1: phase timers of the two kernels (development aid), summed over all streams:
 // 0 stage 1 header 2 warm-up 3 first scan 4 later passes 5 round tail 6 rounds 7 passes
-// 8 expand: records+scan 9 walk 10 copy 11 flush 12 groups 13 stored
+// 8 expand: records+scan 9 walk 10 copy 11 flush 12 groups 13, 14 header read / tables
+// 15 copy: pointer scatter 16 rounds 17 gather 18 number of rounds 19 number of steps
 #ifndef RSX_SPLIT_TIMERS
 #define RSX_SPLIT_TIMERS 0
 #endif
+// A slot is only ever added to by one thread of a workgroup; the sums are kept in LDS (L.tacc) and go
+// to global memory once, when the workgroup ends (an atomic per sample would be timed itself).
 #if RSX_SPLIT_TIMERS
-static __device__ unsigned long long g_split_t[16];
-#define SPLIT_T_ADD(k, v) atomicAdd(&g_split_t[k], (unsigned long long)(v))
+static __device__ unsigned long long g_split_t[24];
+#define SPLIT_T_ADD(k, v) (L.tacc[k] += (unsigned long long)(v))
 #define SPLIT_T_NOW() clock64()
+#define SPLIT_T_FIELD unsigned long long tacc[24];
+#define SPLIT_T_BEGIN() do { if (threadIdx.x < 24) L.tacc[threadIdx.x] = 0; } while (0)
+#define SPLIT_T_END() do { WG_SYNC(); if (threadIdx.x < 24) atomicAdd(&g_split_t[threadIdx.x], L.tacc[threadIdx.x]); } while (0)
 #else
 #define SPLIT_T_ADD(k, v) do { } while (0)
 #define SPLIT_T_NOW() 0ull
+#define SPLIT_T_FIELD
+#define SPLIT_T_BEGIN() do { } while (0)
+#define SPLIT_T_END() do { } while (0)
 #endif
 
 
@@ -204,7 +216,7 @@ struct __align__(16) StreamLdsT {
         TokSpecScratch tspec;
         MatchQueue mq;
     };
-    uint32_t scan_carry[2 * (kT / 64) + 4];   // scans and flags; the last four: the copy phase's spanning match
+    uint32_t scan_carry[3 * (kT / 64) + 4];   // scans and flags; [8..11]: the copy phase's spanning match, then the flags of odd rounds
     uint32_t emit_error;          // min over lanes of lane << 8 | DecompressResult
     uint32_t stat_spec, stat_copy; // pass counters (STATS builds)
     uint32_t first_flag;          // first lane whose sub-sequence ends the block / the input
@@ -219,6 +231,7 @@ struct __align__(16) StreamLdsT {
     int32_t stored_len;   // >= 0: a stored block of that many bytes is pending
     int32_t restage;      // header parse wants the window moved first
     uint64_t bitpos;      // next unread bit, relative to the start of the DEFLATE body
+    SPLIT_T_FIELD
 };
 
 // The serial header code sits behind non-inlined calls.  Its LDS operands carry their
@@ -1075,6 +1088,7 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
     for (uint32_t sub_start = round_start; sub_start < round_end && mcur < nm; sub_start += kCopySub, step++) {
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
+        unsigned long long ts = SPLIT_T_NOW();
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
         // The matches that end inside this step are a prefix of them (matches do not overlap);
         // every wave counts its own, the next step starts behind their sum.  The first lane of a
@@ -1130,6 +1144,7 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
 #pragma unroll
         for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; }
+        if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(15, t - ts); ts = t; SPLIT_T_ADD(19, 1); }
         // Pointer jumping: a pointer into this step that lands on a non-literal byte takes
         // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
         // registers.  A pointer can still move while it points into the step (v < kCopySub)
@@ -1143,12 +1158,17 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         for (int round = 0; round < 16; round++) {
             uint32_t v2[kPer];
             if (RSX_DEV_TIMERS && tid == 0) L.stat_copy++;
+            if (RSX_SPLIT_TIMERS && tid == 0) SPLIT_T_ADD(18, 1);
             // (all reads of a round are issued before the first dependent one is needed)
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
                 v2[k] = ptr[v[k] < kCopySub ? v[k] : kCopySub];
             }
+#if RSX_TWO_BARRIERS
             WG_SYNC();   // every read of this round precedes its writes
+#endif
+            // (no barrier between the reads and the writes: a lane that reads a pointer its owner has
+            // already advanced in this round only gets further along the same chain)
             bool moving = false;
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
@@ -1158,16 +1178,20 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
                 ptr[tid + k * kT] = (uint16_t)v[k];
                 moving = moving || v[k] < kCopySub;
             }
-            // one barrier publishes the new pointers and the waves' "still moving" flags
+            // one barrier publishes the new pointers and the waves' "still moving" flags; odd and even rounds
+            // have their own flags: the wave that is first through the barrier writes its next flag while the
+            // others still read this round's
+            uint32_t *const flags = &L.scan_carry[(round & 1) ? 2 * (kT / 64) + 4 : 4];
             const uint32_t wave_moving = __ballot(moving) != 0;
-            if ((tid & 63) == 0) L.scan_carry[4 + (tid >> 6)] = wave_moving;
+            if ((tid & 63) == 0) flags[tid >> 6] = wave_moving;
             WG_SYNC();
             uint32_t any_moving = 0;
 #pragma unroll
-            for (int k = 0; k < kT / 64; k++) any_moving |= L.scan_carry[4 + k];
+            for (int k = 0; k < kT / 64; k++) any_moving |= flags[k];
             if (!any_moving) break;
         }
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
+        if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(16, t - ts); ts = t; }
         reinterpret_cast<uint4 *>(ptr)[tid] = all_self;   // (nobody reads the table any more in this step)
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
         // bytes that have left the ring (read back from the output)
@@ -1196,6 +1220,7 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         }
         WG_SYNC();
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tc; tc = t; }
+        if (RSX_SPLIT_TIMERS && tid == 0) SPLIT_T_ADD(17, SPLIT_T_NOW() - ts);
     }
     WG_SYNC();
 }
@@ -1503,7 +1528,10 @@ constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence i
 constexpr uint32_t kSegRows = kTokCap / kSegSteps - 1;   // header rows 1..kSegRows: bytes | matches << 16 in front of piece p
 constexpr uint32_t kHdrRows = 1 + kSegRows;
 static_assert(kTokCap % kSegSteps == 0, "whole pieces");
-constexpr uint32_t kLaneBytesStop = 8192; // a sub-sequence stops once it has produced this many bytes
+#ifndef RSX_LANE_BYTES
+#define RSX_LANE_BYTES 8192
+#endif
+constexpr uint32_t kLaneBytesStop = RSX_LANE_BYTES; // a sub-sequence stops once it has produced this many bytes
 static_assert(kLaneBytesStop + 258 <= kRoundOut, "one sub-sequence must fit a round of the expander");
 static_assert(kTokCap <= kMaxMatches, "one sub-sequence must fit the match queue");
 #ifndef RSX_DEC_SUB_BITS
@@ -1762,6 +1790,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     uint64_t seen_bitpos = ~0ull;
     int stalled = 0;
     bool bail = false;
+    SPLIT_T_BEGIN();
     WG_SYNC();
     for (;;) {
         {
@@ -1835,6 +1864,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         status[item] = ok ? kStatusPending : kStatusFallback;
         body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
     }
+    SPLIT_T_END();
 }
 
 // LDS of the second kernel: the output ring, the copy phase's pointer table (named win: copy_round is
@@ -1843,12 +1873,20 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
 #define RSX_XRING 16384
 #endif
 constexpr uint32_t kXRing = RSX_XRING, kXRingMask = kXRing - 1;   // the second kernel's ring
-static_assert((kXRing & kXRingMask) == 0 && kXRing >= kRing && kXRing <= 65536, "a power of two that holds a round");
+static_assert((kXRing & kXRingMask) == 0 && kXRing >= 4096 && kXRing <= 65536, "a power of two that holds a group");
+#ifndef RSX_XMATCHES
+#define RSX_XMATCHES 1792
+#endif
+constexpr uint32_t kXMaxMatches = RSX_XMATCHES;   // match queue entries per group
+static_assert(kTokCap <= kXMaxMatches, "one sub-sequence must fit the match queue");
+struct XMatchQueue {
+    uint16_t dst[kXMaxMatches];   // as MatchQueue
+};
 struct __align__(16) ExpandLds {
     uint32_t win[kWinWords + 4];
     uint8_t ring[kXRing];
-    MatchQueue mq;
-    uint32_t scan_carry[2 * (kT / 64) + 4];
+    XMatchQueue mq;
+    uint32_t scan_carry[3 * (kT / 64) + 4];
     uint32_t stat_copy;
     unsigned long long stat_t[4];
     uint32_t num_matches;
@@ -1858,6 +1896,7 @@ struct __align__(16) ExpandLds {
     uint32_t lane_at[kT];    // per sub-sequence of the round: output bytes in front of it (from the round's start)
     uint16_t lane_mi[kT];    // matches in front of it
     uint8_t lane_steps[kT];  // its decoder steps
+    SPLIT_T_FIELD
 };
 
 #ifndef RSX_XOCC
@@ -1867,7 +1906,7 @@ struct __align__(16) ExpandLds {
 #define RSX_XGROUP (16384 - 16)
 #endif
 constexpr uint32_t kXGroupOut = RSX_XGROUP;   // output bytes per group of the second kernel
-static_assert(kLaneBytesStop + 258 <= kXGroupOut && kXGroupOut <= kRoundOut, "one sub-sequence fits a group, a group the ring");
+static_assert(kLaneBytesStop + 258 <= kXGroupOut && kXGroupOut + 16 <= kXRing, "one sub-sequence fits a group, a group the ring");
 __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
@@ -1906,6 +1945,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     uint32_t flushed = 0;   // output positions below this are in global memory (uniform)
     uint32_t pos = 0;       // output position reached (uniform)
     bool bail = false;
+    SPLIT_T_BEGIN();
     WG_SYNC();
     auto flush_upto = [&](uint32_t upto_pos) {
         uint32_t upto = ((upto_pos + c.shift) & ~15u);
@@ -1928,7 +1968,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
             flush_upto(pos);
             const uint8_t *sp = c.body + src_byte;
             for (uint32_t done = 0; done < len;) {
-                const uint32_t piece = len - done < kRoundOut ? len - done : kRoundOut;
+                const uint32_t piece = len - done < kXGroupOut ? len - done : kXGroupOut;
                 for (uint32_t k = tid; k < piece; k += kT) L.ring[(pos + k + c.shift) & kXRingMask] = sp[done + k];
                 WG_SYNC();
                 pos += piece;
@@ -1959,7 +1999,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
             }
             WG_SYNC();
             const uint32_t bb = L.base_bytes, bn = L.base_nm;
-            const bool fits = exb + bytes - bb <= kXGroupOut && exn + nm - bn <= kMaxMatches;
+            const bool fits = exb + bytes - bb <= kXGroupOut && exn + nm - bn <= kXMaxMatches;
             if ((uint32_t)tid > g0 && (uint32_t)tid < nlanes && !fits) atomicMin(&L.group_end, (uint32_t)tid);
             WG_SYNC();
             const uint32_t g1 = L.group_end;
@@ -2034,6 +2074,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
         status[item] = bail ? kStatusFallback : RSX_SUCCESS;
         out_sizes[item] = bail ? 0 : pos;
     }
+    SPLIT_T_END();
 }
 
 // zlib / gzip trailer check (src/decompress/mod.rs:1104-1120, :1202-1233): the
@@ -2164,7 +2205,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     if (split || !e->inflate_stats) (void)hipEventRecord(e->ev_end, e->stream);
 #if RSX_SPLIT_TIMERS
     if (split) {
-        unsigned long long t[16], z[16] = {0};
+        unsigned long long t[24], z[24] = {0};
         RSX_HIP(e, hipStreamSynchronize(e->stream));
         RSX_HIP(e, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_split_t), sizeof t));
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_split_t), z, sizeof z));
@@ -2173,6 +2214,8 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                         "passes %.0f tail %.0f (header: read %.0f, tables %.0f) | expand groups %.1f cycles: records %.0f walk %.0f copy %.0f flush %.0f\n",
                 t[6] / d, t[7] / d, t[0] / d, t[1] / d, t[2] / d, t[3] / d, t[4] / d, t[5] / d, t[13] / d, t[14] / d, t[12] / d, t[8] / d, t[9] / d,
                 t[10] / d, t[11] / d);
+        fprintf(stderr, "[rsx split] copy per stream: steps %.1f rounds %.1f cycles: scatter %.0f rounds %.0f gather %.0f\n",
+                t[19] / d, t[18] / d, t[15] / d, t[16] / d, t[17] / d);
     }
 #endif
     e->timed = true;
