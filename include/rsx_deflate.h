@@ -88,6 +88,15 @@ int rsx_engine_synchronize(rsx_engine *e);
  * events on the engine's stream.  Synchronises.  Negative if none was run.
  */
 float rsx_engine_last_kernel_ms(rsx_engine *e);
+/*
+ * Number of independently decoded parts of the most recent decompress call: equal to
+ * its number of streams unless large streams were cut at sync-flush joints (the
+ * chunk joints of src/compress/mod.rs:699-772), 0 if the call did not look for
+ * cuts.  Diagnostic; synchronises.
+ */
+uint32_t rsx_engine_last_parts(rsx_engine *e);
+/* ... and how many of its streams were decoded as a whole after all because a part of them did not stand by itself */
+uint32_t rsx_engine_last_whole(rsx_engine *e);
 
 /* Compressor::{deflate,zlib,gzip}_compress_bound, src/compress/mod.rs:2236-2246 */
 uint64_t rsx_compress_bound(int format, uint64_t len);

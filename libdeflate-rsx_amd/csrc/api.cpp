@@ -11,6 +11,7 @@
 int ws_reserve(rsx_engine *e, size_t bytes)
 {
     e->ws_used = 0;
+    e->d_last_parts = nullptr;   // (points into the workspace this call carves anew)
     e->arena = e->ws;
     e->arena_size = e->ws_size;
     if (bytes <= e->ws_size) return RSX_OK;
@@ -37,6 +38,7 @@ int ws_reserve(rsx_engine *e, size_t bytes)
 int ws_use_static(rsx_engine *e, size_t bytes)
 {
     e->ws_used = 0;
+    e->d_last_parts = nullptr;
     e->arena = e->static_scratch;
     e->arena_size = e->static_scratch_size;
     if (!e->static_scratch || bytes > e->static_scratch_size) {
@@ -140,6 +142,7 @@ int rsx_engine_create(int device, void *stream, rsx_engine **out)
     e->num_cus = prop.multiProcessorCount;
     e->inflate_stats = getenv("RSX_INFLATE_STATS") != nullptr;
     e->inflate_split = getenv("RSX_INFLATE_FUSED") == nullptr && !e->inflate_stats;
+    e->inflate_parts = getenv("RSX_INFLATE_WHOLE") == nullptr;
     *out = e;
     return RSX_OK;
 }
@@ -177,6 +180,29 @@ float rsx_engine_last_kernel_ms(rsx_engine *e)
     if (hipEventSynchronize(e->ev_end) != hipSuccess) return -1.0f;
     if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) != hipSuccess) return -1.0f;
     return ms;
+}
+
+static bool last_part_words(rsx_engine *e, uint32_t v[3])
+{
+    v[0] = v[1] = v[2] = 0;
+    if (!e) return false;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->d_last_parts) return false;
+    DeviceGuard g(e->device);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    return hipMemcpy(v, e->d_last_parts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+}
+
+uint32_t rsx_engine_last_parts(rsx_engine *e)
+{
+    uint32_t v[3];
+    return last_part_words(e, v) ? v[0] : 0;
+}
+
+uint32_t rsx_engine_last_whole(rsx_engine *e)
+{
+    uint32_t v[3];
+    return last_part_words(e, v) ? v[1] + v[2] : 0;
 }
 
 uint64_t rsx_compress_bound(int format, uint64_t len)

@@ -34,9 +34,12 @@ struct rsx_engine {
     int num_cus = 0;           // multiprocessors of this engine's GPU
     bool inflate_stats = false;  // RSX_INFLATE_STATS was set when the engine was created
     bool inflate_split = true;   // two-kernel decoder (RSX_INFLATE_FUSED=1 at engine creation turns it off)
+    bool inflate_parts = true;   // few large streams are cut at sync-flush markers (RSX_INFLATE_WHOLE=1 turns it off)
 
     // constant tables in device memory (built once in rsx_engine_create)
     uint32_t *d_crc_tables = nullptr;  // see checksum.hip for the layout
+
+    const uint32_t *d_last_parts = nullptr;   // device word: parts of the last decompress call (in the workspace)
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;

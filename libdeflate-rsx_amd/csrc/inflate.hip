@@ -1554,6 +1554,10 @@ struct RoundRec {
     uint32_t c;         //                                        stored: high half
 };
 
+// A stream owns one token row per 512 bits of its input (and the longest round on top).  Text whose blocks
+// are a megabyte long needs a row per 850 bits; every block end cuts a round short, so streams of 64 KiB
+// blocks need one per 550, and one per 1024 sent a third of them to the one-kernel decoder.
+constexpr uint32_t kRowBitsLog2 = 9;
 // where a stream's token rows and round records live (both kernels compute the same)
 struct SplitLayout {
     uint32_t *tok;          // token rows of all streams
@@ -1561,13 +1565,13 @@ struct SplitLayout {
     // rel = the stream's input offset minus the batch's first
     __device__ uint64_t first_row(uint64_t rel, uint32_t item) const
     {
-        return (rel * 8 >> 10) + (uint64_t)item * (kTokCap + kHdrRows + 1);
+        return (rel * 8 >> kRowBitsLog2) + (uint64_t)item * (kTokCap + kHdrRows + 1);
     }
-    __device__ uint64_t row_budget(uint64_t in_len) const { return (in_len * 8 >> 10) + kTokCap + kHdrRows; }
+    __device__ uint64_t row_budget(uint64_t in_len) const { return (in_len * 8 >> kRowBitsLog2) + kTokCap + kHdrRows; }
     __device__ uint64_t first_round(uint64_t rel, uint32_t item) const { return (rel >> 8) + (uint64_t)item * 66; }
     __device__ uint64_t round_budget(uint64_t in_len) const { return (in_len >> 8) + 64; }
 };
-static inline uint64_t split_tok_rows(size_t n, uint64_t total_in) { return (total_in * 8 >> 10) + n * (kTokCap + kHdrRows + 1) + 2; }
+static inline uint64_t split_tok_rows(size_t n, uint64_t total_in) { return (total_in * 8 >> kRowBitsLog2) + n * (kTokCap + kHdrRows + 1) + 2; }
 static inline uint64_t split_round_recs(size_t n, uint64_t total_in) { return (total_in >> 8) + n * 66 + 2; }
 
 typedef StreamLdsT<kDecWinBytes, 16> DecodeLds;
@@ -1621,7 +1625,8 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
 // (uniform) the number of rows the round used, header row included, or 0 when it must not be recorded
 // (an error: L.status is set).  *sub_next receives the sub-sequence length to use for the next round.
 __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_t win_bit0, uint32_t sub_bits,
-                                        uint32_t *__restrict__ rows, uint32_t *nlanes_ret, uint32_t *sub_next)
+                                        uint32_t *__restrict__ rows, uint32_t *nlanes_ret, uint32_t *sub_next,
+                                        uint32_t *bytes_ret)
 {
     constexpr uint32_t kWinLimitBits = DecodeLds::kWinLimitBits;
     const int tid = threadIdx.x;
@@ -1732,6 +1737,7 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
         *sub_next = max(s, kDecSubMin);
     }
     *nlanes_ret = last + 1;
+    *bytes_ret = by;
     if (tid == 0) {
         L.bitpos = (uint64_t)(win_bit0 + (int64_t)(last_exit & kExitPosMask));
         if (last_exit & kExitStop) {
@@ -1749,14 +1755,25 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
 #ifndef RSX_DEC_OCC
 #define RSX_DEC_OCC 6
 #endif
+// parts != nullptr: the items are the parts of cut streams (see "Streams cut into parts" below): *parts->count
+// of them, the ones marked kStatusFallback beforehand are left alone, a part with open_end set ends well when
+// its input ends between two blocks, and every part reports the bytes its tokens produce.
+struct DecodeParts {
+    const uint32_t *count;
+    const uint8_t *open_end;
+    uint64_t *bytes;
+};
 __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, int32_t *__restrict__ status, uint64_t *__restrict__ body_end, SplitLayout lay,
-    const uint64_t *__restrict__ in_hi, const uint64_t *__restrict__ in_base_p)
+    const uint64_t *__restrict__ in_hi, const uint64_t *__restrict__ in_base_p, DecodeParts parts)
 {
     __shared__ DecodeLds L;
     const uint32_t item = blockIdx.x;
     if (item >= n) return;
+    if (parts.count && (item >= *parts.count || status[item] == kStatusFallback)) return;   // (uniform)
+    const bool open_end = parts.open_end && parts.open_end[item];
+    uint64_t produced = 0;   // output bytes of the tokens and stored blocks so far (uniform)
     const int tid = threadIdx.x;
     const uint64_t ib = in_off[item], ie = in_hi[item];
     StreamCtx c;
@@ -1766,7 +1783,9 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     c.out = nullptr;
     c.out_cap = 0;
     c.shift = 0;
-    const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
+    // (an item that does not lie inside the batch's bytes would put its token rows anywhere)
+    const bool inside = ib >= in_base && ie >= ib && ie - in_base <= total_in;
+    const ContainerInfo ci = inside ? parse_container(format, in + ib, ie - ib) : ContainerInfo{0, 0, RSX_BAD_DATA};
     if (ci.status >= 0) {   // (uniform) inflate_kernel reports it
         if (tid == 0) status[item] = kStatusFallback;
         return;
@@ -1795,6 +1814,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     for (;;) {
         {
             const uint64_t bp = L.bitpos;
+            const bool between = !L.in_block && L.stored_len < 0;
             stalled = bp == seen_bitpos ? stalled + 1 : 0;
             seen_bitpos = bp;
             WG_SYNC();
@@ -1802,9 +1822,16 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
                 bail = true;
                 break;
             }
+            // a part of a cut stream ends where the next one starts: between two blocks, at the last bit of
+            // its input
+            if (open_end && between && bp != 0 && bp == c.body_len * 8) {
+                if (tid == 0) L.status = RSX_SUCCESS;
+                WG_SYNC();
+                break;
+            }
         }
-        // room for one more round and its record, and for the end record behind it
-        if (row + kTokCap + kHdrRows > row_budget || nrounds + 2 > round_budget) {
+        // room for one more round record and for the end record behind it
+        if (nrounds + 2 > round_budget) {
             bail = true;
             break;
         }
@@ -1828,8 +1855,15 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         }
         if (st0 < 0 && stored0 < 0) {
             if (b0 + sub_bits + 64 > DecodeLds::kWinLimitBits) continue;
-            uint32_t nlanes = 0, sub_next = sub_bits;
-            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, tok + row * kT, &nlanes, &sub_next);
+            // room for the longest round of tokens (asked only where tokens follow: a stored block needs no rows)
+            if (row + kTokCap + kHdrRows > row_budget) {
+                bail = true;
+                break;
+            }
+            uint32_t nlanes = 0, sub_next = sub_bits, round_bytes = 0;
+            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, tok + row * kT, &nlanes, &sub_next,
+                                                      &round_bytes);
+            produced += round_bytes;
             sub_bits = sub_next;
             if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, 0};
             row += used;
@@ -1845,6 +1879,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
                 bail = true;   // ShortInput
                 break;
             }
+            produced += (uint64_t)stored;
             if (tid == 0) {
                 rounds[nrounds] = RoundRec{ROUND_STORED, (uint32_t)stored, (uint32_t)src_byte, (uint32_t)(src_byte >> 32)};
                 L.stored_len = -1;
@@ -1863,6 +1898,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         if (ok) rounds[nrounds] = RoundRec{ROUND_END, 0, 0, 0};
         status[item] = ok ? kStatusPending : kStatusFallback;
         body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
+        if (parts.bytes) parts.bytes[item] = produced;
     }
     SPLIT_T_END();
 }
@@ -1911,11 +1947,11 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
     int32_t *__restrict__ status, SplitLayout lay, const uint64_t *__restrict__ in_hi,
-    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p)
+    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p, const uint32_t *__restrict__ count)
 {
     __shared__ ExpandLds L;
     const uint32_t item = blockIdx.x;
-    if (item >= n) return;
+    if (item >= n || (count && item >= *count)) return;
     if (status[item] != kStatusPending) return;   // (uniform)
     const int tid = threadIdx.x;
     const uint64_t ib = in_off[item], ie = in_hi[item];
@@ -2108,6 +2144,263 @@ __global__ void verify_trailer_kernel(int format, const uint8_t *__restrict__ in
     }
 }
 
+// =====================================================================================
+// Streams cut into parts.  One stream is decoded by one workgroup, so a batch of a few large streams
+// leaves most of the GPU idle.  The reference's compressor cuts inputs above 256 KiB into chunks that
+// it compresses independently and joins with sync-flush markers (src/compress/mod.rs:699-772: an empty
+// stored block, byte aligned, 00 00 FF FF), and so does this engine's; a decoder that stands between two
+// blocks at a byte boundary can start there without knowing anything of what came before, as long as no
+// match reaches back across the joint.  For batches of few, large streams the input is therefore
+// searched for the marker (the first one in every 32 KiB tile), and every stretch between two finds is
+// decoded as a part of its own by the two kernels above.  The marker is only a hint: a part is accepted
+// when its decoder arrives, between two blocks, at exactly the byte where the next part starts (the last
+// part: at the final block's end), and when no match of it reaches in front of its first byte.  Then the
+// parts' sizes give their places in the stream's output slot, the second kernel expands them side by
+// side, and the stream is reported like any other.  A stream with a part that fails any of this is
+// decoded again as a whole by the one-kernel decoder, which also reports every error.
+constexpr uint32_t kPartTile = 32768;        // at most one cut per tile of the flat input
+constexpr int32_t kStatusSkip = -4;          // a part whose stream is left to inflate_kernel
+constexpr uint64_t kNoBody = ~0ull;
+
+// per stream: the DEFLATE body [body_lo, body_hi) as offsets into `in` (kNoBody: the container is damaged)
+__global__ void part_items_kernel(int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
+                                  uint32_t n, uint64_t *__restrict__ body_lo, uint64_t *__restrict__ body_hi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ib = in_off[i], ie = in_off[i + 1];
+    const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
+    const bool ok = ci.status < 0 && (uint64_t)ci.hdr + ci.trailer <= ie - ib;
+    body_lo[i] = ok ? ib + ci.hdr : kNoBody;
+    body_hi[i] = ok ? ie - ci.trailer : kNoBody;
+}
+
+// one workgroup per tile: the first marker that starts in the tile, the stream it lies in, and whether the
+// byte behind it lies inside that stream's body (then a part can start there)
+__global__ __launch_bounds__(kT) void part_find_kernel(
+    const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n, uint64_t total_in,
+    const uint64_t *__restrict__ body_lo, const uint64_t *__restrict__ body_hi, uint64_t *__restrict__ tile_first,
+    uint32_t *__restrict__ tile_item, uint32_t *__restrict__ tile_flag)
+{
+    __shared__ uint32_t first;   // offset of the earliest marker from the tile's first word
+    const uint32_t b = blockIdx.x;
+    const uint64_t base = in_off[0];
+    const uint64_t t0 = base + (uint64_t)b * kPartTile;   // the tile is in[t0, t1)
+    const uint64_t end = base + total_in;
+    const uint64_t t1 = t0 + kPartTile < end ? t0 + kPartTile : end;
+    if (threadIdx.x == 0) first = ~0u;
+    WG_SYNC();
+    // aligned words from the one that holds in[t0] on; a word that holds a byte of the input is readable
+    const uintptr_t a0 = (uintptr_t)(in + t0) & ~(uintptr_t)3;
+    const uintptr_t a_end = (uintptr_t)(in + end);
+    const uint32_t lead = (uint32_t)((uintptr_t)(in + t0) - a0);   // bytes of the first word in front of the tile
+    const __attribute__((address_space(1))) uint32_t *w = (const __attribute__((address_space(1))) uint32_t *)a0;
+    const uint32_t nwords = (uint32_t)((t1 - t0 + lead + 3) / 4);
+    for (uint32_t k = threadIdx.x; k < nwords; k += kT) {
+        const uint32_t lo = w[k];
+        const uint32_t hi = a0 + 4ull * (k + 1) < a_end ? w[k + 1] : 0u;
+        const uint64_t v = ((uint64_t)hi << 32) | lo;
+#pragma unroll
+        for (uint32_t sft = 0; sft < 4; sft++) {
+            const uint32_t at = 4 * k + sft;   // from a0
+            // 00 00 FF FF starting at this byte, inside the tile and whole inside the input
+            if ((uint32_t)(v >> (8 * sft)) == 0xFFFF0000u && at >= lead && t0 + (at - lead) < t1 &&
+                t0 + (at - lead) + 4 <= end)
+                atomicMin(&first, at - lead);
+        }
+    }
+    WG_SYNC();
+    if (threadIdx.x == 0) {
+        const uint32_t f = first;
+        uint64_t start = 0;
+        uint32_t item = 0, flag = 0;
+        if (f != ~0u) {
+            const uint64_t at = t0 + f;   // where the marker starts
+            start = at + 4;
+            // the stream that holds the marker's first byte: the last i with in_off[i] <= at
+            uint32_t lo_i = 0, hi_i = n;   // in_off[lo_i] <= at < in_off[hi_i]
+            while (hi_i - lo_i > 1) {
+                const uint32_t mid = lo_i + (hi_i - lo_i) / 2;
+                if (in_off[mid] <= at) lo_i = mid; else hi_i = mid;
+            }
+            item = lo_i;
+            const uint64_t bl = body_lo[item], bh = body_hi[item];
+            flag = bl != kNoBody && at >= bl && start < bh;
+        }
+        tile_first[b] = start;
+        tile_item[b] = item;
+        tile_flag[b] = flag;
+    }
+}
+
+// exclusive prefix sums of the tiles' flags (one workgroup); *count = streams + cuts = number of parts
+__global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ tile_flag, uint32_t ntiles,
+                                                         uint32_t n, uint32_t *__restrict__ tile_pre,
+                                                         uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    WG_SYNC();
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = i < ntiles ? tile_flag[i] : 0u;
+        uint32_t x = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)(threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+        WG_SYNC();
+        uint32_t before = carry;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) before += wsum[k];
+        if (i < ntiles) tile_pre[i] = before + x - c;
+        WG_SYNC();
+        if (threadIdx.x == 1023) carry = before + x;
+        WG_SYNC();
+    }
+    if (threadIdx.x == 0) {
+        tile_pre[ntiles] = carry;
+        count[0] = n + carry;
+        count[1] = 0;   // streams taken out behind the first kernel
+        count[2] = 0;   // ... behind the second
+    }
+}
+
+// The parts in the order of their first bytes: stream starts and cuts merged.  Cut b comes behind the
+// starts of streams 0..item and behind the cuts of earlier tiles; the start of stream i comes behind i
+// earlier starts and the cuts that lie in earlier streams.
+__global__ void part_scatter_kernel(const uint64_t *__restrict__ in_off, uint32_t n, uint64_t total_in,
+                                    uint32_t ntiles, const uint64_t *__restrict__ body_lo,
+                                    const uint64_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_item,
+                                    const uint32_t *__restrict__ tile_flag, const uint32_t *__restrict__ tile_pre,
+                                    uint64_t *__restrict__ part_lo, uint32_t *__restrict__ part_parent)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) {
+        if (!tile_flag[t]) return;
+        const uint32_t idx = tile_pre[t] + tile_item[t] + 1;
+        part_lo[idx] = tile_first[t];
+        part_parent[idx] = tile_item[t];
+        return;
+    }
+    const uint32_t i = t - ntiles;
+    if (i >= n) return;
+    const uint64_t rel = in_off[i] - in_off[0];
+    uint32_t before;   // cuts that lie in streams in front of this one
+    if (rel >= total_in) {
+        before = tile_pre[ntiles];
+    } else {
+        const uint32_t tb = (uint32_t)(rel / kPartTile);
+        before = tile_pre[tb] + ((tile_flag[tb] && tile_item[tb] < i) ? 1u : 0u);
+    }
+    const uint64_t bl = body_lo[i];
+    part_lo[i + before] = bl != kNoBody ? bl : in_off[i];
+    part_parent[i + before] = i;
+}
+
+// per part: where its input ends, whether it is the last of its stream; per stream: its first part
+__global__ void part_finish_kernel(uint32_t n, const uint32_t *__restrict__ count, const uint64_t *__restrict__ body_hi,
+                                   uint64_t *__restrict__ part_lo, const uint32_t *__restrict__ part_parent,
+                                   uint64_t *__restrict__ part_hi, uint8_t *__restrict__ part_open,
+                                   int32_t *__restrict__ part_status, uint32_t *__restrict__ parent_first)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t np = *count;
+    if (s >= np) return;
+    const uint32_t p = part_parent[s];
+    if (p >= n) {   // (cannot happen: every slot below *count is written by part_scatter_kernel)
+        part_hi[s] = part_lo[s] = 0;
+        part_open[s] = 0;
+        part_status[s] = kStatusSkip;
+        return;
+    }
+    const bool last = s + 1 == np || part_parent[s + 1] != p;
+    const uint64_t bh = body_hi[p];
+    part_hi[s] = bh == kNoBody ? part_lo[s] : last ? bh : part_lo[s + 1];
+    part_open[s] = last ? 0 : 1;
+    part_status[s] = bh == kNoBody ? kStatusFallback : kStatusPending;   // (the first kernel overwrites it)
+    if (s == 0 || part_parent[s - 1] != p) parent_first[p] = s;
+}
+
+// Behind the first kernel, per stream: every part must have decoded, every part but the last must have
+// used its input to the last byte, and the sum of the parts' bytes must fit the stream's slot.  Then the
+// parts get their places in the slot; else all of them are taken out and the stream is marked for
+// inflate_kernel.
+__global__ void part_place_kernel(const uint64_t *__restrict__ out_off, uint32_t n, const uint32_t *__restrict__ count,
+                                  const uint32_t *__restrict__ parent_first, const uint32_t *__restrict__ part_parent,
+                                  const uint64_t *__restrict__ part_lo, const uint64_t *__restrict__ part_hi,
+                                  const uint64_t *__restrict__ part_used, const uint64_t *__restrict__ part_bytes,
+                                  int32_t *__restrict__ part_status, uint64_t *__restrict__ part_olo,
+                                  uint64_t *__restrict__ part_ohi, int32_t *__restrict__ status,
+                                  uint32_t *__restrict__ taken_out)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t np = *count, s0 = parent_first[p];
+    const uint64_t cap = out_off[p + 1] - out_off[p];
+    bool ok = true;
+    uint64_t total = 0;
+    uint32_t s1 = s0;
+    for (; s1 < np && part_parent[s1] == p; s1++) {
+        const bool last = s1 + 1 == np || part_parent[s1 + 1] != p;
+        if (part_status[s1] != kStatusPending) ok = false;
+        else if (!last && part_used[s1] != part_hi[s1] - part_lo[s1]) ok = false;
+        else total += part_bytes[s1];
+        if (total > cap) ok = false;
+        if (!ok) break;
+    }
+    if (ok) {
+        uint64_t at = out_off[p];
+        for (uint32_t s = s0; s < s1; s++) {
+            part_olo[s] = at;
+            at += part_bytes[s];
+            part_ohi[s] = at;
+        }
+        status[p] = kStatusPending;
+    } else {
+        for (uint32_t s = s0; s < np && part_parent[s] == p; s++) {
+            part_status[s] = kStatusSkip;
+            part_olo[s] = part_ohi[s] = out_off[p];
+        }
+        status[p] = kStatusFallback;
+        atomicAdd(taken_out, 1u);
+    }
+}
+
+// Behind the second kernel, per stream: all parts expanded -> the stream's size, status and the end of its
+// DEFLATE body; else it is marked for inflate_kernel.
+__global__ void part_reduce_kernel(const uint64_t *__restrict__ in_off, uint32_t n, const uint32_t *__restrict__ count,
+                                   const uint32_t *__restrict__ parent_first, const uint32_t *__restrict__ part_parent,
+                                   const uint64_t *__restrict__ part_lo, const uint64_t *__restrict__ part_used,
+                                   const int32_t *__restrict__ part_status, const uint64_t *__restrict__ part_sizes,
+                                   uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status,
+                                   uint64_t *__restrict__ body_end, uint32_t *__restrict__ taken_out)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    out_sizes[p] = 0;
+    body_end[p] = 0;
+    if (status[p] != kStatusPending) return;   // (already marked for inflate_kernel)
+    const uint32_t np = *count;
+    bool ok = true;
+    uint64_t total = 0;
+    uint32_t last = parent_first[p];
+    for (uint32_t s = last; s < np && part_parent[s] == p; s++) {
+        if (part_status[s] != RSX_SUCCESS) ok = false;
+        total += part_sizes[s];
+        last = s;
+    }
+    if (ok) {
+        status[p] = RSX_SUCCESS;
+        out_sizes[p] = total;
+        body_end[p] = (part_lo[last] - in_off[p]) + part_used[last];
+    } else {
+        status[p] = kStatusFallback;
+        atomicAdd(taken_out, 1u);
+    }
+}
+
 // Scratch of rsx_batch_decompress_device_noalloc: every GPU the library runs on holds its own copy
 // of this array until the process ends; host code reaches it only through the address that
 // inflate_static_scratch() looks up.
@@ -2131,12 +2424,31 @@ static size_t inflate_common_ws_bytes(size_t n, uint64_t total_out)
            checksum_ws_bytes(n, total_out) + 1024;
 }
 
+// Number of tiles the input is searched in for cuts, 0 when the batch is decoded stream by stream: cutting
+// pays for few, large streams (many streams fill the GPU by themselves, and every part costs token rows).
+static uint32_t inflate_part_tiles(size_t n, uint64_t total_in)
+{
+    if (n > 1024 || total_in < (1u << 20) || total_in > (1ull << 32) || total_in / n < (256u << 10)) return 0;
+    return (uint32_t)((total_in + kPartTile - 1) / kPartTile);
+}
+
+static size_t inflate_parts_ws_bytes(size_t n, uint32_t ntiles)
+{
+    const size_t cap = n + ntiles;
+    return 3 * align_up(n * 8, 256) + align_up(ntiles * 8, 256) + 3 * align_up((ntiles + 1) * 4, 256) + 256 +
+           7 * align_up(cap * 8, 256) + 2 * align_up(cap * 4, 256) + align_up(cap, 256);
+}
+
 size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool split)
 {
     size_t b = inflate_common_ws_bytes(n, total_out);
-    if (split)
-        b += align_up(split_tok_rows(n, total_in) * kT * sizeof(uint32_t), 256) +
-             align_up(split_round_recs(n, total_in) * sizeof(RoundRec), 256);
+    if (split) {
+        const uint32_t ntiles = inflate_part_tiles(n, total_in);
+        const size_t items = n + ntiles;
+        b += align_up(split_tok_rows(items, total_in) * kT * sizeof(uint32_t), 256) +
+             align_up(split_round_recs(items, total_in) * sizeof(RoundRec), 256);
+        if (ntiles) b += inflate_parts_ws_bytes(n, ntiles);
+    }
     return b;
 }
 
@@ -2157,10 +2469,13 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     }
     uint64_t *body_end = static_cast<uint64_t *>(ws_take(e, n * sizeof(uint64_t)));
     uint32_t *sums = static_cast<uint32_t *>(ws_take(e, n * sizeof(uint32_t)));
+    // streams cut into parts: only for the usual layout (an item's slices could overlap a neighbour's)
+    const uint32_t ntiles = split && !slices && e->inflate_parts ? inflate_part_tiles(n, total_in) : 0u;
+    const size_t items = n + (split && !slices ? inflate_part_tiles(n, total_in) : 0u);   // (as inflate_ws_bytes counts)
     SplitLayout lay{nullptr, nullptr};
     if (split) {
-        lay.tok = static_cast<uint32_t *>(ws_take(e, split_tok_rows(n, total_in) * kT * sizeof(uint32_t)));
-        lay.rounds = static_cast<RoundRec *>(ws_take(e, split_round_recs(n, total_in) * sizeof(RoundRec)));
+        lay.tok = static_cast<uint32_t *>(ws_take(e, split_tok_rows(items, total_in) * kT * sizeof(uint32_t)));
+        lay.rounds = static_cast<RoundRec *>(ws_take(e, split_round_recs(items, total_in) * sizeof(RoundRec)));
     }
     if (!body_end || !sums || (split && (!lay.tok || !lay.rounds))) {
         e->err = "workspace exhausted";
@@ -2168,11 +2483,58 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     }
     const uint32_t grid = (uint32_t)n;
     (void)hipEventRecord(e->ev_begin, e->stream);
-    if (split) {
+    e->d_last_parts = nullptr;
+    if (ntiles) {
+        const size_t cap = n + ntiles;
+        auto take64 = [&](size_t k) { return static_cast<uint64_t *>(ws_take(e, k * 8)); };
+        auto take32 = [&](size_t k) { return static_cast<uint32_t *>(ws_take(e, k * 4)); };
+        uint64_t *body_lo = take64(n), *body_hi = take64(n), *tile_first = take64(ntiles);
+        uint32_t *parent_first = take32(2 * n);   // (8 bytes per stream reserved)
+        uint32_t *tile_item = take32(ntiles + 1), *tile_flag = take32(ntiles + 1), *tile_pre = take32(ntiles + 1);
+        uint32_t *count = take32(64);
+        uint64_t *part_lo = take64(cap), *part_hi = take64(cap), *part_olo = take64(cap), *part_ohi = take64(cap);
+        uint64_t *part_used = take64(cap), *part_bytes = take64(cap), *part_sizes = take64(cap);
+        uint32_t *part_parent = take32(cap);
+        int32_t *part_status = reinterpret_cast<int32_t *>(take32(cap));
+        uint8_t *part_open = static_cast<uint8_t *>(ws_take(e, cap));
+        if (!body_lo || !body_hi || !tile_first || !parent_first || !tile_item || !tile_flag || !tile_pre || !count ||
+            !part_lo || !part_hi || !part_olo || !part_ohi || !part_used || !part_bytes || !part_sizes || !part_parent ||
+            !part_status || !part_open) {
+            e->err = "workspace exhausted";
+            return RSX_E_NOMEM;
+        }
+        e->d_last_parts = count;
+        const uint32_t pgrid = (uint32_t)cap, tb = 256;
+        part_items_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(format, in, in_off, grid, body_lo, body_hi);
+        part_find_kernel<<<ntiles, kT, 0, e->stream>>>(in, in_off, grid, total_in, body_lo, body_hi, tile_first,
+                                                       tile_item, tile_flag);
+        part_scan_kernel<<<1, 1024, 0, e->stream>>>(tile_flag, ntiles, grid, tile_pre, count);
+        part_scatter_kernel<<<(pgrid + tb - 1) / tb, tb, 0, e->stream>>>(in_off, grid, total_in, ntiles, body_lo,
+                                                                         tile_first, tile_item, tile_flag, tile_pre,
+                                                                         part_lo, part_parent);
+        part_finish_kernel<<<(pgrid + tb - 1) / tb, tb, 0, e->stream>>>(grid, count, body_hi, part_lo, part_parent, part_hi,
+                                                                        part_open, part_status, parent_first);
+        // the parts are raw DEFLATE items given as slices; their token rows are laid out by their own numbers
+        inflate_decode_kernel<<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, total_in,
+                                                           part_status, part_used, lay, part_hi, in_off,
+                                                           DecodeParts{count, part_open, part_bytes});
+        part_place_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(out_off, grid, count, parent_first, part_parent,
+                                                                      part_lo, part_hi, part_used, part_bytes,
+                                                                      part_status, part_olo, part_ohi, status, count + 1);
+        inflate_expand_kernel<<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
+                                                           part_sizes, part_status, lay, part_hi, part_ohi, in_off,
+                                                           count);
+        part_reduce_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(in_off, grid, count, parent_first, part_parent,
+                                                                       part_lo, part_used, part_status, part_sizes,
+                                                                       out_sizes, status, body_end, count + 2);
+        inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
+                                                          status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
+                                                          in_base_p);
+    } else if (split) {
         inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
-                                                          in_hi, in_base_p);
+                                                          in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
         inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
-                                                          lay, in_hi, out_hi, in_base_p);
+                                                          lay, in_hi, out_hi, in_base_p, nullptr);
         // whatever the two left (damaged streams, slots that are too small, streams that need more
         // token space than the workspace has) is decoded again by the one-kernel decoder
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,

@@ -266,3 +266,70 @@ def test_gzip_files_with_several_members(rsx, eng):
     # the single-member entry point stops behind the first member, like the reference
     got, st = eng.batch_decompress([gz[0] + gz[1]], [700000], rsx.FORMAT_GZIP)
     assert got == [parts[0]] and st[0] == 0
+
+
+# ---- few large streams: cut at sync-flush joints and decoded part by part ------------------
+
+def test_large_streams_are_cut_into_parts(rsx, eng):
+    # src/compress/mod.rs:699-772: inputs above 256 KiB are compressed in independent 256 KiB chunks joined by
+    # sync-flush markers; the decoder starts one part per joint it finds (at most one per 32 KiB of input)
+    data = corpus.text(3 << 20, 11) + corpus.mixed(1 << 20, 12) + corpus.json_like(1 << 20, 13)
+    for fmt in (rsx.FORMAT_DEFLATE, rsx.FORMAT_ZLIB, rsx.FORMAT_GZIP):
+        stream = o.compress(data, 6, fmt)
+        got, status = eng.batch_decompress([stream], [len(data)], fmt)
+        assert list(status) == [0] and got[0] == data
+        assert 18 <= eng.last_parts() <= (len(data) + (1 << 18) - 1) >> 18, eng.last_parts()   # one part per chunk
+        assert eng.last_whole() == 0
+    # the engine's own compressor produces the same joints
+    comp, cstatus = eng.batch_compress([data], rsx.FORMAT_GZIP, 6)
+    assert list(cstatus) == [0]
+    got, status = eng.batch_decompress(comp, [len(data)], rsx.FORMAT_GZIP)
+    assert list(status) == [0] and got[0] == data and eng.last_parts() > 8 and eng.last_whole() == 0
+
+
+def test_parts_with_history_across_the_joint_fall_back(rsx, eng):
+    # zlib's Z_SYNC_FLUSH keeps the window: matches behind the joint reach in front of it, so the parts cannot
+    # be expanded side by side; Z_FULL_FLUSH forgets it.  Either way the bytes are zlib's.
+    data = corpus.text(2 << 20, 21)
+    for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        stream = b""
+        for at in range(0, len(data), 200000):
+            stream += co.compress(data[at:at + 200000]) + co.flush(flush)
+        stream += co.flush()
+        got, status = eng.batch_decompress([stream, stream], [len(data), len(data) + 5], rsx.FORMAT_DEFLATE)
+        assert list(status) == [0, 0] and got == [data, data]
+        assert eng.last_parts() >= 2 and eng.last_whole() == (2 if flush == zlib.Z_SYNC_FLUSH else 0)
+
+
+def test_parts_and_false_joints(rsx, eng):
+    # the marker bytes inside stored data and inside a gzip header field are not joints; a stream cut short,
+    # a slot that is too small and damaged parts report what the oracle reports
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    marked = bytearray(noise)
+    for at in range(1000, len(marked) - 8, 50000):
+        marked[at:at + 4] = b"\x00\x00\xff\xff"
+    marked = bytes(marked)
+    text = corpus.text(1 << 20, 31)
+    mixed = text + marked + text
+    co, c0 = zlib.compressobj(6, zlib.DEFLATED, 31), zlib.compressobj(0, zlib.DEFLATED, 31)
+    streams = [c0.compress(marked) + c0.flush(), co.compress(mixed) + co.flush()]   # stored blocks hold the noise
+    caps = [len(marked), len(mixed)]
+    good = o.compress(text + text, 6, o.FMT_GZIP)
+    streams += [good[:len(good) // 2], good, good[:-9] + b"\x00" + good[-8:], good]
+    caps += [2 * len(text), 2 * len(text) - 1, 2 * len(text), 2 * len(text) + 100]
+    damaged = bytearray(good)
+    damaged[len(good) // 3] ^= 0x55
+    streams.append(bytes(damaged))
+    caps.append(2 * len(text))
+    check_against_oracle(eng, streams, caps, rsx.FORMAT_GZIP)
+    assert eng.last_parts() > len(streams)
+
+
+def test_parts_are_off_for_many_streams(rsx, eng):
+    data = [corpus.text(300000, 40 + i) for i in range(4)]
+    streams = [o.compress(d, 1) for d in data] * 275
+    got, status = eng.batch_decompress(streams, [300000] * len(streams))
+    assert not any(status) and got[:4] == data[:4] and got[-4:] == data[:4]
+    assert eng.last_parts() == 0
