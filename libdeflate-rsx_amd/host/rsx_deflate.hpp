@@ -19,8 +19,10 @@
 #ifndef RSX_DEFLATE_HPP
 #define RSX_DEFLATE_HPP
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <memory>
 #include <optional>
@@ -52,7 +54,7 @@ struct BytesMut {
 };
 
 // io::ErrorKind values the reference's api.rs produces
-enum class ErrorKind { InvalidInput, InvalidData, Other };
+enum class ErrorKind { InvalidInput, InvalidData, UnexpectedEof, Other };
 
 class Error : public std::runtime_error {
   public:
@@ -445,6 +447,81 @@ class DeflateEncoder {
     std::vector<uint8_t> buffer_, out_;
     size_t buffer_size_ = 1024 * 1024;
     bool finished_ = false;
+};
+
+// libdeflate::stream::DeflateDecoder<R> (src/stream.rs:235-377): reads one raw DEFLATE stream from a
+// reader and hands out the decompressed bytes through read().  Reader is anything callable as
+// size_t reader(uint8_t *dst, size_t cap) that returns 0 at the end of its data.  The reference feeds
+// a resumable CPU decoder through a 64 KiB window (src/decompress/mod.rs:213-353); the GPU decodes
+// whole streams, so the first read() pulls the reader dry and decodes everything at once (a large
+// stream is cut at its sync-flush joints and decoded part by part), growing the output until the
+// stream fits.  What read() returns afterwards is what the reference returns, byte for byte; an
+// error is reported by the first read() instead of after the bytes in front of it:
+// BadData -> InvalidData "deflate decompression failed" (:329-333), a stream that ends early ->
+// UnexpectedEof "unexpected EOF" (:359-370), an empty reader -> read() returns 0 (:371).
+template <class Reader>
+class DeflateDecoder {
+  public:
+    explicit DeflateDecoder(Reader inner, std::shared_ptr<Engine> engine = nullptr)
+        : inner_(std::move(inner)), engine_(std::move(engine))
+    {
+    }
+    // io::Read::read: up to buf.size bytes, 0 at the end of the stream
+    size_t read(BytesMut buf)
+    {
+        if (!decoded_) decode_all();
+        const size_t count = std::min(buf.size, out_.size() - read_pos_);
+        if (count) std::memcpy(buf.data, out_.data() + read_pos_, count);
+        read_pos_ += count;
+        return count;
+    }
+    // everything that is left (io::Read::read_to_end)
+    std::vector<uint8_t> read_to_end()
+    {
+        if (!decoded_) decode_all();
+        std::vector<uint8_t> rest(out_.begin() + (std::ptrdiff_t)read_pos_, out_.end());
+        read_pos_ = out_.size();
+        return rest;
+    }
+
+  private:
+    void decode_all()
+    {
+        decoded_ = true;
+        std::vector<uint8_t> in;
+        for (;;) {   // (the reference's input buffer also doubles as it fills, src/stream.rs:346-352)
+            const size_t at = in.size(), room = std::max<size_t>(32 * 1024, at);
+            in.resize(at + room);
+            const size_t n = inner_(in.data() + at, room);
+            in.resize(at + n);
+            if (n == 0) break;
+        }
+        if (in.empty()) return;   // nothing to decode: read() returns 0
+        if (!engine_) engine_ = Engine::shared();
+        // DEFLATE expands at most 1032 : 1 (a 258-byte match per two bits and a bit)
+        const uint64_t most = (uint64_t)in.size() * 1032 + 65536;
+        for (uint64_t cap = std::max<uint64_t>(4 * (uint64_t)in.size(), 65536);; cap = std::min(2 * cap, most)) {
+            out_.resize((size_t)cap);
+            const uint64_t in_off[2] = {0, in.size()}, out_off[2] = {0, cap};
+            uint64_t size = 0;
+            int32_t status = 0;
+            engine_->check(rsx_batch_decompress(engine_->handle(), RSX_FORMAT_DEFLATE, in.data(), in_off, 1, out_.data(),
+                                                out_off, &size, &status));
+            if (status == RSX_SUCCESS && size <= cap) {
+                out_.resize((size_t)size);
+                return;
+            }
+            if (status == RSX_INSUFFICIENT_SPACE && cap < most) continue;
+            out_.clear();
+            if (status == RSX_SHORT_INPUT) throw Error(ErrorKind::UnexpectedEof, "unexpected EOF");
+            throw Error(ErrorKind::InvalidData, "deflate decompression failed");
+        }
+    }
+    Reader inner_;
+    std::shared_ptr<Engine> engine_;
+    std::vector<uint8_t> out_;
+    size_t read_pos_ = 0;
+    bool decoded_ = false;
 };
 
 // crate-level checksums (src/lib.rs:15-17): pass the previous result to continue one

@@ -311,6 +311,72 @@ static void test_stream_encoder()
     CHECK(oracle_inflates_to(z, big, ORC_FMT_DEFLATE));
 }
 
+// src/stream.rs:235-377: the decoder hands out, through reads of any size, exactly the bytes the stream
+// holds; its errors carry the reference's kinds and messages
+static void test_stream_decoder()
+{
+    Buf text = make_text(2 * 1024 * 1024 + 777, 41);
+    rsx::Compressor c(6);
+    const Buf z = c.compress_deflate(text);   // (several chunks: the decoder cuts the stream at their joints)
+    auto reader_over = [](const Buf &src, size_t step) {
+        auto at = std::make_shared<size_t>(0);
+        return [&src, at, step](uint8_t *dst, size_t cap) {
+            const size_t n = std::min(std::min(cap, step), src.size() - *at);
+            if (n) std::memcpy(dst, src.data() + *at, n);
+            *at += n;
+            return n;
+        };
+    };
+    for (size_t step : {size_t(1) << 30, size_t(4097), size_t(100000)}) {
+        auto reader = reader_over(z, step);
+        rsx::DeflateDecoder<decltype(reader)> dec(reader);
+        Buf got, piece(70001);
+        for (;;) {   // ragged reads
+            const size_t n = dec.read(rsx::BytesMut(piece.data(), 1 + got.size() % piece.size()));
+            if (n == 0) break;
+            got.insert(got.end(), piece.begin(), piece.begin() + n);
+        }
+        CHECK(got == text);
+        CHECK(dec.read(piece) == 0);   // stays at the end
+    }
+    {
+        auto reader = reader_over(z, 65536);
+        rsx::DeflateDecoder<decltype(reader)> dec(reader);
+        Buf head(1000);
+        CHECK(dec.read(head) == 1000 && std::equal(head.begin(), head.end(), text.begin()));
+        const Buf rest = dec.read_to_end();
+        CHECK(rest.size() == text.size() - 1000 && std::equal(rest.begin(), rest.end(), text.begin() + 1000));
+    }
+    const Buf empty;
+    {
+        auto reader = reader_over(empty, 100);
+        rsx::DeflateDecoder<decltype(reader)> dec(reader);
+        Buf piece(10);
+        CHECK(dec.read(piece) == 0);   // an empty reader is an empty stream (src/stream.rs:365-371)
+    }
+    const Buf cut(z.begin(), z.begin() + z.size() / 2);
+    Buf damaged = z;
+    damaged[damaged.size() / 3] ^= 0x40;
+    damaged[damaged.size() / 3 + 1] ^= 0x04;
+    for (int which = 0; which < 2; which++) {
+        const Buf &src = which ? damaged : cut;
+        auto reader = reader_over(src, 50000);
+        rsx::DeflateDecoder<decltype(reader)> dec(reader);
+        Buf piece(100);
+        // what the oracle says about the stream decides which error it must be
+        std::vector<uint8_t> scratch(text.size());
+        size_t used = 0, produced = 0;
+        const int r = orc_decompress(ORC_FMT_DEFLATE, src.data(), src.size(), scratch.data(), scratch.size(), &used, &produced);
+        try {
+            dec.read(piece);
+            CHECK(r == 0);
+        } catch (const rsx::Error &e) {
+            if (r == 4) CHECK(e.kind() == rsx::ErrorKind::UnexpectedEof && std::string(e.what()) == "unexpected EOF");
+            else CHECK(r != 0 && e.kind() == rsx::ErrorKind::InvalidData && std::string(e.what()) == "deflate decompression failed");
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const bool no_gpu = argc > 1 && std::strcmp(argv[1], "--no-gpu") == 0;
@@ -322,6 +388,7 @@ int main(int argc, char **argv)
             test_batch_failures();
             test_one_shot_api();
             test_stream_encoder();
+            test_stream_decoder();
         } catch (const std::exception &e) {
             std::fprintf(stderr, "FAILED: unexpected exception: %s\n", e.what());
             g_failed++;
