@@ -333,3 +333,35 @@ def test_parts_are_off_for_many_streams(rsx, eng):
     got, status = eng.batch_decompress(streams, [300000] * len(streams))
     assert not any(status) and got[:4] == data[:4] and got[-4:] == data[:4]
     assert eng.last_parts() == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_parts_random_flush_patterns(rsx, eng, seed):
+    """Streams of one to four MiB with flushes of every kind at random places (full flushes and chunk joints
+    can be cut, sync flushes keep their history, block flushes are no joints at all), stored stretches, in all
+    three containers, some cut short or with a slot one byte too small: status and bytes must be the oracle's."""
+    rs = np.random.RandomState(seed)
+    kinds = [zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_NO_FLUSH, zlib.Z_FULL_FLUSH]
+    if hasattr(zlib, "Z_BLOCK"):
+        kinds.append(zlib.Z_BLOCK)
+    for fmt in (0, 1, 2):
+        streams, caps = [], []
+        for k in range(4):
+            size = int(rs.randint(1 << 20, 4 << 20))
+            pieces = [corpus.text(size // 2, 100 * seed + k), corpus.random_bytes(size // 8, seed + k),
+                      corpus.json_like(size - size // 2 - size // 8, 7 * seed + k)]
+            data = b"".join(pieces)
+            co = zlib.compressobj(int(rs.choice([1, 6, 9])), zlib.DEFLATED, WBITS[fmt])
+            out, at = [], 0
+            while at < len(data):
+                n = int(rs.randint(1000, 400000))
+                out.append(co.compress(data[at:at + n]))
+                out.append(co.flush(int(rs.choice(kinds))) if rs.randint(0, 3) else b"")
+                at += n
+            out.append(co.flush())
+            s = b"".join(out)
+            own = eng.batch_compress([data], fmt, 6)[0][0]   # (chunk joints; the incompressible chunk as stored blocks)
+            streams += [s, s[:int(rs.randint(1, len(s)))], s, own]
+            caps += [len(data), len(data), len(data) - 1, len(data)]
+        check_against_oracle(eng, streams, caps, fmt)
+        assert eng.last_parts() > len(streams)
