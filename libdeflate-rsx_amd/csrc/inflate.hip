@@ -2190,23 +2190,29 @@ __global__ __launch_bounds__(kT) void part_find_kernel(
     const uint64_t t1 = t0 + kPartTile < end ? t0 + kPartTile : end;
     if (threadIdx.x == 0) first = ~0u;
     WG_SYNC();
-    // aligned words from the one that holds in[t0] on; a word that holds a byte of the input is readable
-    const uintptr_t a0 = (uintptr_t)(in + t0) & ~(uintptr_t)3;
+    // aligned 16-byte units from the one that holds in[t0] on (a unit that holds a byte of the input is
+    // readable: it does not cross a page), one unit per lane and turn, plus the word behind it
+    const uintptr_t a0 = (uintptr_t)(in + t0) & ~(uintptr_t)15;
     const uintptr_t a_end = (uintptr_t)(in + end);
-    const uint32_t lead = (uint32_t)((uintptr_t)(in + t0) - a0);   // bytes of the first word in front of the tile
-    const __attribute__((address_space(1))) uint32_t *w = (const __attribute__((address_space(1))) uint32_t *)a0;
-    const uint32_t nwords = (uint32_t)((t1 - t0 + lead + 3) / 4);
-    for (uint32_t k = threadIdx.x; k < nwords; k += kT) {
-        const uint32_t lo = w[k];
-        const uint32_t hi = a0 + 4ull * (k + 1) < a_end ? w[k + 1] : 0u;
-        const uint64_t v = ((uint64_t)hi << 32) | lo;
+    const uint32_t lead = (uint32_t)((uintptr_t)(in + t0) - a0);   // bytes of the first unit in front of the tile
+    const uint32_t nunits = (uint32_t)((t1 - t0 + lead + 15) / 16);
+    for (uint32_t k = threadIdx.x; k < nunits; k += kT) {
+        const uintptr_t ua = a0 + 16ull * k;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = *(const __attribute__((address_space(1))) u32x4 *)ua;
+        const uint32_t next = ua + 16 < a_end ? *(const __attribute__((address_space(1))) uint32_t *)(ua + 16) : 0u;
+        const uint32_t w[5] = {q.x, q.y, q.z, q.w, next};
 #pragma unroll
-        for (uint32_t sft = 0; sft < 4; sft++) {
-            const uint32_t at = 4 * k + sft;   // from a0
-            // 00 00 FF FF starting at this byte, inside the tile and whole inside the input
-            if ((uint32_t)(v >> (8 * sft)) == 0xFFFF0000u && at >= lead && t0 + (at - lead) < t1 &&
-                t0 + (at - lead) + 4 <= end)
-                atomicMin(&first, at - lead);
+        for (uint32_t d = 0; d < 4; d++) {
+            const uint64_t v = ((uint64_t)w[d + 1] << 32) | w[d];
+#pragma unroll
+            for (uint32_t sft = 0; sft < 4; sft++) {
+                const uint32_t at = 16 * k + 4 * d + sft;   // from a0
+                // 00 00 FF FF starting at this byte, inside the tile and whole inside the input
+                if ((uint32_t)(v >> (8 * sft)) == 0xFFFF0000u && at >= lead && t0 + (at - lead) < t1 &&
+                    t0 + (at - lead) + 4 <= end)
+                    atomicMin(&first, at - lead);
+            }
         }
     }
     WG_SYNC();
@@ -2426,9 +2432,12 @@ static size_t inflate_common_ws_bytes(size_t n, uint64_t total_out)
 
 // Number of tiles the input is searched in for cuts, 0 when the batch is decoded stream by stream: cutting
 // pays for few, large streams (many streams fill the GPU by themselves, and every part costs token rows).
+#ifndef RSX_PARTS_MAX_N
+#define RSX_PARTS_MAX_N 65536
+#endif
 static uint32_t inflate_part_tiles(size_t n, uint64_t total_in)
 {
-    if (n > 1024 || total_in < (1u << 20) || total_in > (1ull << 32) || total_in / n < (256u << 10)) return 0;
+    if (n > RSX_PARTS_MAX_N || total_in < (1u << 20) || total_in > (1ull << 32) || total_in / n < (256u << 10)) return 0;
     return (uint32_t)((total_in + kPartTile - 1) / kPartTile);
 }
 

@@ -327,7 +327,8 @@ def test_parts_and_false_joints(rsx, eng):
     assert eng.last_parts() > len(streams)
 
 
-def test_parts_are_off_for_many_streams(rsx, eng):
+def test_parts_are_off_for_short_streams(rsx, eng):
+    # (streams that average less than 256 KiB of input are not searched for joints)
     data = [corpus.text(300000, 40 + i) for i in range(4)]
     streams = [o.compress(d, 1) for d in data] * 275
     got, status = eng.batch_decompress(streams, [300000] * len(streams))

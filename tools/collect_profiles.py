@@ -14,8 +14,8 @@ import sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 base, dest = "gpurun_out/prof", "profiles/" + rnd
 os.makedirs(dest, exist_ok=True)
-DOMINANT = {"decompress": ("inflate_decode_kernel", "inflate_expand_kernel"), "compress": ("deflate_chunks_kernel", "deflate_emit_kernel")}
-OURS = ("inflate_", "deflate_", "checksum_", "verify_trailer", "chunk_scan", "seg_scan")
+DOMINANT = {"decompress": ("inflate_decode_kernel", "inflate_expand_kernel", "part_"), "compress": ("deflate_chunks_kernel", "deflate_emit_kernel")}
+OURS = ("inflate_", "deflate_", "checksum_", "verify_trailer", "chunk_scan", "seg_scan", "part_")
 
 
 def short(name):
