@@ -37,8 +37,8 @@ for op in ("decompress", "compress"):
         print(op, short(r["Name"])[:48], r["Calls"], "%.3f ms" % (float(r["AverageNs"]) / 1e6))
     per = collections.defaultdict(lambda: [0.0, set()])
     for tag in ("fetch", "write", "sq1", "sq2"):
-        fs = glob.glob("%s/%s_%s/**/*counter_collection.csv" % (base, op, tag), recursive=True)
-        for cf in fs:
+        # (gpurun merges every run's files into gpurun_out/: only the newest pass of a tag counts)
+        for cf in [newest("%s/%s_%s/**/*counter_collection.csv" % (base, op, tag))]:
             for r in csv.DictReader(open(cf)):
                 k = short(r["Kernel_Name"])
                 if not k.startswith(OURS):
