@@ -1547,22 +1547,31 @@ __device__ inline ChunkPlace place_chunk(const uint64_t *in_off, uint32_t n, con
     return c;
 }
 
-// Match kernel.  Persistent workgroups: workgroup g takes chunks g, g + gridDim.x, ...; per chunk
-// the token units go to tokbuf + chunk * tok_stride, the block table to blk_tab / blk_hist +
-// chunk * kMaxBlocks entries, the number of blocks to chunk_blocks.
+// Match kernel.  Persistent workgroups that take the next chunk from a counter (*next_chunk, zero at the
+// launch) whenever they are done with one: chunks differ in cost, and with a fixed stride a workgroup
+// whose chunks are all of the slow kind (a batch of repeating buffers does that) holds the kernel up.  What
+// a chunk compresses to does not depend on who takes it.  Per chunk the token units go to tokbuf +
+// chunk * tok_stride, the block table to blk_tab / blk_hist + chunk * kMaxBlocks entries, the number of
+// blocks to chunk_blocks.
 template <bool kOptimal, bool kChains>
 __global__ __launch_bounds__(kCT) void deflate_chunks_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, LevelParams lp,
     uint64_t scratch_stride, uint16_t *__restrict__ tokbuf, uint64_t tok_stride,
     uint2 *__restrict__ blk_tab, uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ chunk_blocks,
-    uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf)
+    uint32_t *__restrict__ pairbuf, uint8_t *__restrict__ costbuf, uint32_t *__restrict__ next_chunk)
 {
     __shared__ ChunkLds L;
+    __shared__ uint32_t taken;
     uint32_t *mp = pairbuf ? pairbuf + (size_t)blockIdx.x * kChunk * kPairs : nullptr;
     uint8_t *blkcost = costbuf + (size_t)blockIdx.x * kMaxBlocks * kBlkCostStride;
     const uint32_t total_chunks = chunk_first[n];
-    for (uint32_t ch = blockIdx.x; ch < total_chunks && ch < chunk_slots; ch += gridDim.x) {
+    for (;;) {
+        if (threadIdx.x == 0) taken = atomicAdd(next_chunk, 1u);
+        WG_SYNC();
+        const uint32_t ch = taken;
+        WG_SYNC();   // (everyone has read it before the next turn overwrites it)
+        if (ch >= total_chunks || ch >= chunk_slots) break;
         const ChunkPlace c = place_chunk(in_off, n, chunk_first, ch);
         // the caller understated the longest item: the chunk has no room in the token buffer or
         // in the chunk scratch (the emit kernel makes the item fall back or fail)
@@ -1876,7 +1885,7 @@ size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int leve
            align_up(chunks * kMaxBlocks * kHistStride * 2, 256) + align_up((chunks + 1) * 4, 256) +
            checksum_ws_bytes(n, total_in) + pairs +
            align_up((size_t)1024 * kMaxBlocks * kBlkCostStride, 256) + align_up((chunks + 1) * 8, 256) +
-           align_up((n + 1) * 4, 256) + 4096;
+           align_up((n + 1) * 4, 256) + 256 + 4096;
 }
 
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,
@@ -1906,6 +1915,7 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
     uint8_t *costbuf = static_cast<uint8_t *>(ws_take(e, (size_t)grid * kMaxBlocks * kBlkCostStride));
     uint64_t *chunk_dst = static_cast<uint64_t *>(ws_take(e, (chunks + 1) * 8));
     uint32_t *item_mode = static_cast<uint32_t *>(ws_take(e, (n + 1) * 4));
+    uint32_t *next_chunk = static_cast<uint32_t *>(ws_take(e, 256));
     uint32_t *pairbuf = nullptr;
     if (level >= 10) {
         pairbuf = static_cast<uint32_t *>(ws_take(e, (size_t)grid * kChunk * kPairs * 4));
@@ -1915,17 +1925,19 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
         }
     }
     if (!scratch || !chunk_size || !chunk_first || !tokbuf || !blk_tab || !blk_hist || !chunk_blocks || !sums ||
-        !costbuf || !chunk_dst || !item_mode) {
+        !costbuf || !chunk_dst || !item_mode || !next_chunk) {
         e->err = "workspace exhausted";
         return RSX_E_NOMEM;
     }
     LevelParams lp = level_params(level);
     chunk_scan_kernel<<<1, 1024, 0, e->stream>>>(in_off, (uint32_t)n, chunk_first);
+    RSX_HIP(e, hipMemsetAsync(next_chunk, 0, sizeof(uint32_t), e->stream));
     (void)hipEventRecord(e->ev_begin, e->stream);
 #define RSX_LAUNCH_CHUNKS(OPT, CH)                                                                          \
     deflate_chunks_kernel<OPT, CH><<<grid, kCT, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first,       \
                                                                 (uint32_t)chunks, lp, stride, tokbuf, tok_units, \
-                                                                blk_tab, blk_hist, chunk_blocks, pairbuf, costbuf)
+                                                                blk_tab, blk_hist, chunk_blocks, pairbuf, costbuf, \
+                                                                next_chunk)
     if (level == 0) { /* stored blocks only: nothing to match */ }
     else if (lp.optimal) RSX_LAUNCH_CHUNKS(true, true);
     else if (lp.chains) RSX_LAUNCH_CHUNKS(false, true);
