@@ -202,6 +202,10 @@ struct __align__(16) EmitLds {
     alignas(16) uint32_t pj[640 + 160];   // node depths, then the run-length items of the header
 };
 
+// Orders the LDS traffic of one wave: its lanes run in step and the LDS serves a wave's requests in
+// order, so this only has to keep the compiler from moving accesses across.
+#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 // ---- bit output -------------------------------------------------------------------
 // Token units (16 bits each, in the workgroup's token buffer): a literal is its byte value, a
 // match is a length unit kUnitLen | (len - 3) followed by a distance unit kUnitDist | (dist - 1).
@@ -1300,41 +1304,47 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
             }
             x_ntoks = 1;
         }
-        // pointer jumping over slots 0..kCT (slot kCT+1 = beyond)
+        // Which slots start a token: the chain entry -> next(entry) -> ... over slots 0..kCT (slot kCT+1 =
+        // beyond).  Every wave first squares the pointers of its own 64 slots through lane exchanges, six times,
+        // which needs no barrier: that leaves, per slot, the slot at which its chain leaves the wave's segment,
+        // and on the way the 2^k-th successors inside the segment.  The exits go to LDS (the one barrier of the
+        // phase); every wave follows them from the batch's entry to its own segment, then marks its part of
+        // the chain: marked slots mark their 2^k-th successor, k = 0..5, through the wave's own bytes of
+        // L.mark.  (Pointer jumping over the whole batch took nine rounds with a barrier each, on a CU that
+        // holds one workgroup.)
         const uint32_t entry_slot = entry - base_pos;   // entry >= base_pos (b0 = 0: entry 0 -> slot 1)
-        // every slot's owner sets its mark: 1 only for the slot the parse enters the batch at
-        const uint32_t enter = entry_slot < lim ? entry_slot : ~0u;
-        L.jump[0][tid] = (uint16_t)(my_next > kEnd ? kEnd : my_next);
-        L.mark[tid] = (uint32_t)tid == enter;
-        if (tid == kCT - 1) {
-            L.jump[0][kCT] = (uint16_t)(x_next > kEnd ? kEnd : x_next);
-            L.jump[0][kEnd] = (uint16_t)kEnd;
-            L.mark[kCT] = enter == (uint32_t)kCT;
-            L.mark[kEnd] = 0;
-        }
-        WG_SYNC();
-        int cur = 0;
-        for (uint32_t span = 1; span < kCT + 2; span <<= 1) {
-            // marked slots mark their 2^k-th successor; then square the jump table
-            const uint32_t s = tid;
-            uint32_t j = L.jump[cur][s];
-            uint32_t jx = (tid == kCT - 1) ? L.jump[cur][kCT] : kEnd;
-            bool mk = L.mark[s] != 0, mkx = (tid == kCT - 1) && L.mark[kCT] != 0;
-            // no barrier between reading and setting marks: a slot that sees its own mark set
-            // earlier in the same step only marks its successor (a token start as well) a step
-            // early; the jump tables are double-buffered
-            if (mk && j < lim) L.mark[j] = 1;
-            if (mkx && jx < lim) L.mark[jx] = 1;
-            L.jump[cur ^ 1][s] = L.jump[cur][j];
-            if (tid == kCT - 1) {
-                L.jump[cur ^ 1][kCT] = L.jump[cur][jx];
-                L.jump[cur ^ 1][kEnd] = (uint16_t)kEnd;
+        {
+            const uint32_t lane = tid & 63, seg0 = (uint32_t)tid & ~63u, seg1 = seg0 + 64;
+            uint32_t jk[6];   // 2^k-th successor (a slot of a later segment stays as it is)
+            uint32_t j = my_next > kEnd ? kEnd : my_next;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                jk[k] = j;
+                const bool inside = j < seg1;
+                const uint32_t t = (uint32_t)__shfl((int)j, inside ? (int)(j - seg0) : (int)lane);
+                j = inside ? t : j;
             }
+            L.jump[0][tid] = (uint16_t)j;   // where the chain through this slot leaves the segment
             WG_SYNC();
-            cur ^= 1;
-            // the entry's pointer now spans 2 * span tokens: once it leaves the decided range
-            // every token start of the batch is marked (uniform: all lanes read the same word)
-            if (entry_slot >= lim || L.jump[cur][entry_slot] >= lim) break;
+            uint32_t e = entry_slot;   // (the same for every lane of the wave)
+            while (e < seg0 && e < lim && e < (uint32_t)kCT) e = L.jump[0][e];
+            const uint32_t mine = (e >= seg0 && e < seg1 && e < lim) ? e : ~0u;
+            if (tid == kCT - 1) {
+                // slot kCT (the chunk ends with this batch) belongs to no segment: the chain reaches it or not
+                const uint32_t out = mine != ~0u ? (uint32_t)L.jump[0][mine] : e;
+                L.mark[kCT] = out == (uint32_t)kCT && (uint32_t)kCT < lim;
+                L.mark[kEnd] = 0;
+            }
+            bool marked = (uint32_t)tid == mine;
+            L.mark[tid] = marked;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                WAVE_SYNC();
+                if (marked && jk[k] < seg1 && jk[k] < lim) L.mark[jk[k]] = 1;
+                WAVE_SYNC();
+                marked = L.mark[tid] != 0;
+            }
+            WAVE_SYNC();
         }
         DT_MARK(3);
         // emit the tokens of marked slots in position order
