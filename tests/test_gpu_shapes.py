@@ -263,12 +263,14 @@ def test_understated_max_out_still_decodes(eng, rsx):
         assert d_out.cpu().numpy().tobytes() == b"".join(texts)
 
 
-def test_device_batch_with_an_offset_base_and_unaligned_slots(eng, rsx):
+@pytest.mark.parametrize("sizes", [(70001, 33333, 120007), (1200007, 900001, 2000003)])
+def test_device_batch_with_an_offset_base_and_unaligned_slots(eng, rsx, sizes):
     # in_off[0] != 0 (the batch is a slice of a larger buffer) and output slots at odd addresses: the bytes
-    # of the batch are in[in_off[0] .. in_off[n]), and the last stream must read all of its own
+    # of the batch are in[in_off[0] .. in_off[n]), and the last stream must read all of its own; the large
+    # streams are also cut into parts at their chunk joints
     import torch
     dev = torch.device("cuda", 0)
-    texts = [corpus.text(70001, 730), corpus.mixed(33333, 731), corpus.text(120007, 732)]
+    texts = [corpus.text(sizes[0], 730), corpus.mixed(sizes[1], 731), corpus.text(sizes[2], 732)]
     for fmt, ofmt in ((rsx.FORMAT_DEFLATE, 0), (rsx.FORMAT_GZIP, 2)):
         streams = [o.compress(t, 6, ofmt) for t in texts]
         n = len(texts)
@@ -297,3 +299,5 @@ def test_device_batch_with_an_offset_base_and_unaligned_slots(eng, rsx):
             out = d_out.cpu().numpy()
             assert out[3:int(out_off[-1])].tobytes() == b"".join(texts)
             assert (out[:3] == 0x77).all() and (out[int(out_off[-1]):] == 0x77).all()
+            if call == e2.batch_decompress_device and sizes[0] > (1 << 20):
+                assert e2.last_parts() == sum((x + (1 << 18) - 1) >> 18 for x in sizes) and e2.last_whole() == 0
