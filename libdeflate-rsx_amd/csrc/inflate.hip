@@ -1511,19 +1511,20 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
 // only ever finish streams that decode cleanly.
 //
 // Token array of a stream: rows of 256 words.  A round of the first kernel owns a header
-// row (word l: decoder steps | matches << 8 | output bytes << 16 of sub-sequence l), kSegRows rows of
-// running totals (row p: output bytes | matches << 16 of the first 16 p steps of every sub-sequence,
+// row (word l: tokens | matches << 8 | output bytes << 16 of sub-sequence l), kSegRows rows of
+// running totals (row p: output bytes | matches << 16 of the first 16 p tokens of every sub-sequence,
 // so that the second kernel can start in the middle of one), and then
-// as many rows as its longest sub-sequence took decoder steps; row k holds what the k-th step of
-// every sub-sequence finished: a literal's byte, a match (1 << 31 | distance - 1 << 8 |
-// length - 3) or kNoTok (a length still waiting for its distance, a subtable hop, the end of
-// the block).  A row per step, not per token, keeps the lanes of a wave on the same row: every
-// store is one contiguous 256 bytes.  Rounds are listed in a per-stream array of RoundRec.
+// as many rows as its longest sub-sequence has tokens; row k holds the k-th token of
+// every sub-sequence: a literal's byte, or a match (1 << 31 | distance - 1 << 8 | length - 3).
+// A decoder step that finishes no token (a length still waiting for its distance, a subtable hop,
+// the end of the block) writes nothing.  A row per token of every lane keeps the stores of a wave
+// close together (lanes that are a token apart write neighbouring rows).  Rounds are listed in a
+// per-stream array of RoundRec.
 
 constexpr int32_t kStatusPending = -2;    // decoded into tokens, not expanded yet
 constexpr int32_t kStatusFallback = -3;   // left to inflate_kernel
-constexpr uint32_t kTokCap = 96;          // decoder steps (token slots) per sub-sequence and round
-constexpr uint32_t kNoTok = 0x100;        // a slot whose step finished no token
+constexpr uint32_t kTokCap = 96;          // tokens per sub-sequence and round
+constexpr uint32_t kNoTok = 0x100;        // (second kernel) a slot behind a sub-sequence's last token
 constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence in pieces of this many steps
 constexpr uint32_t kSegRows = kTokCap / kSegSteps - 1;   // header rows 1..kSegRows: bytes | matches << 16 in front of piece p
 constexpr uint32_t kHdrRows = 1 + kSegRows;
@@ -1534,11 +1535,14 @@ static_assert(kTokCap % kSegSteps == 0, "whole pieces");
 constexpr uint32_t kLaneBytesStop = RSX_LANE_BYTES; // a sub-sequence stops once it has produced this many bytes
 static_assert(kLaneBytesStop + 258 <= kRoundOut, "one sub-sequence must fit a round of the expander");
 static_assert(kTokCap <= kMaxMatches, "one sub-sequence must fit the match queue");
+// Sub-sequence lengths are odd multiples of 32 bits: lane i starts at word i * length / 32 of the window, and
+// with an odd stride the 64 lanes of a wave start in 64 different LDS banks (448 bits = 14 words: two lanes
+// per bank, 4.69 ms for the bench's decode kernel; 480 bits: 4.32 ms; 512 bits, 16 lanes per bank: 5.02 ms).
 #ifndef RSX_DEC_SUB_BITS
-#define RSX_DEC_SUB_BITS 448
+#define RSX_DEC_SUB_BITS 480
 #endif
 #ifndef RSX_DEC_WARM_BITS
-#define RSX_DEC_WARM_BITS 896
+#define RSX_DEC_WARM_BITS 1024
 #endif
 constexpr uint32_t kDecSubMax = RSX_DEC_SUB_BITS;      // longest sub-sequence (bits)
 constexpr uint32_t kDecSubMin = 32;
@@ -1579,7 +1583,7 @@ typedef RSX_LDS DecodeLds LdsDecode;
 
 struct TokScan {
     uint32_t exit;   // where the next sub-sequence starts (window bit) | kExit* flags
-    uint32_t info;   // steps | matches << 8 | bytes << 16
+    uint32_t info;   // tokens | matches << 8 | bytes << 16
 };
 
 // scan_span that also writes the tokens it decodes: hdr = this sub-sequence's word of the round's first
@@ -1594,7 +1598,7 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
     const uint32_t end32 = end_b < 0 ? 0u : end_b > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)end_b;
     uint32_t tok = start;   // where the token in flight starts
     uint32_t bytes = 0, nm = 0, kind = kTokNone;
-    uint32_t steps = 0;   // (the same in every lane that is still running)
+    uint32_t ntok = 0;   // tokens written: a step that finishes none (a length, a subtable hop) writes nothing
     bool over = false, full = false;
     bool running = start < bound;
     while (running) {
@@ -1604,18 +1608,18 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
         const bool is_match = kind == kTokMatch;
         const bool fin = kind >= kTokLit && !over;   // a literal or a match ends with this step, inside the body
         const uint32_t rec = is_match ? (0x80000000u | ((o.value - 1) << 8) | (o.len - 3)) : o.value;
-        col[steps * kT] = fin ? rec : kNoTok;
-        steps++;
+        if (fin) col[ntok * kT] = rec;
+        ntok += fin ? 1u : 0u;
         bytes += fin ? (is_match ? o.len : 1u) : 0u;
         nm += (fin && is_match) ? 1u : 0u;
-        if ((steps & (kSegSteps - 1)) == 0) hdr[(steps / kSegSteps) * kT] = bytes | (nm << 16);   // (uniform)
+        if (fin && (ntok & (kSegSteps - 1)) == 0) hdr[(ntok / kSegSteps) * kT] = bytes | (nm << 16);
         tok = fin ? d.b : tok;
         // (a sub-sequence stops early only at the end of a token)
-        full = fin && (steps + 4 >= kTokCap || bytes >= kLaneBytesStop);
+        full = fin && (ntok + 4 >= kTokCap || bytes >= kLaneBytesStop);
         running = !over && kind != kTokEob && !full && (kind < kTokLit || d.b < bound);
     }
     TokScan r;
-    r.info = steps | (nm << 8) | (bytes << 16);
+    r.info = ntok | (nm << 8) | (bytes << 16);
     r.exit = over ? (tok | kExitStop) : kind == kTokEob ? (d.b | kExitEob) : (full && d.b < bound) ? (d.b | kExitFull) : d.b;
     return r;
 }
@@ -1731,10 +1735,11 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
     // next round: aim at 5/8 of the token limit and 3/4 of the byte limit per sub-sequence
     {
         uint32_t s = kDecSubMax;
-        if (tk) s = min(s, (uint32_t)((uint64_t)consumed * (kTokCap * 5 / 8) / tk));   // (tk: decoder steps)
+        if (tk) s = min(s, (uint32_t)((uint64_t)consumed * (kTokCap * 5 / 8) / tk));   // (tk: tokens)
         if (by) s = min(s, (uint32_t)((uint64_t)consumed * (kLaneBytesStop * 3 / 4) / by));
         if (last_exit & kExitFull) s = min(s, sub_bits / 2);
-        *sub_next = max(s, kDecSubMin);
+        s = max(s, kDecSubMin);
+        *sub_next = (((s >> 5) - 1) | 1u) << 5;   // the largest odd multiple of 32 that is not above it
     }
     *nlanes_ret = last + 1;
     *bytes_ret = by;
@@ -1931,7 +1936,7 @@ struct __align__(16) ExpandLds {
     uint32_t bail;
     uint32_t lane_at[kT];    // per sub-sequence of the round: output bytes in front of it (from the round's start)
     uint16_t lane_mi[kT];    // matches in front of it
-    uint8_t lane_steps[kT];  // its decoder steps
+    uint8_t lane_steps[kT];  // its tokens
     SPLIT_T_FIELD
 };
 
