@@ -1,5 +1,5 @@
 """Differential fuzz of the GPU inflater against the oracle (run on a GPU box from the repo root):
-python tools/fuzz_gpu.py [seconds] [first_seed] [compress].  Streams come from zlib with every strategy and level,
+python tools/fuzz_gpu.py [seconds] [first_seed] [compress|parts].  Streams come from zlib with every strategy and level,
 from the oracle's compressor, and from damaged copies of both; every status code and every decoded byte
 must agree.  Prints one line per seed and stops at the first disagreement."""
 import os
@@ -96,7 +96,85 @@ def main():
     eng = rsx.default_engine()
     if len(sys.argv) > 3 and sys.argv[3] == "compress":
         return fuzz_compress(eng, rsx, budget, seed)
+    if len(sys.argv) > 3 and sys.argv[3] == "parts":
+        return fuzz_parts(eng, budget, seed)
     return fuzz_inflate(eng, budget, seed)
+
+
+def big_data(rs):
+    """Megabytes that do not compress far, so that the compressed streams are long enough to be cut."""
+    n = int(rs.randint(1 << 19, 5 << 20))
+    kind = rs.randint(0, 4)
+    if kind == 0:
+        return corpus.mixed(n, int(rs.randint(0, 1 << 20)))
+    if kind == 1:
+        return rs.randint(0, 256, size=n, dtype=np.uint8).tobytes()
+    if kind == 2:
+        p = rs.uniform(0.9, 0.99) ** np.arange(256)
+        return rs.choice(256, size=n, p=p / p.sum()).astype(np.uint8).tobytes()
+    a = rs.randint(0, 256, size=n, dtype=np.uint8)
+    a[rs.randint(0, n, size=n // 3)] = 0    # stray 00 00 FF FF look-alikes inside blocks
+    a[rs.randint(0, n, size=n // 3)] = 255
+    return a.tobytes()
+
+
+def fuzz_parts(eng, budget, seed, max_seeds=1 << 30):
+    """Few long streams with flushes of every kind at random places, so that the batch is cut at its
+    sync-flush joints on the device; damaged copies make parts fail in the middle of a stream."""
+    t0 = time.time()
+    total, cut, last = 0, 0, seed + max_seeds
+    while time.time() - t0 < budget and seed < last:
+        rs = np.random.RandomState(seed)
+        fmt = int(rs.randint(0, 3))
+        streams, caps = [], []
+        for _ in range(int(rs.randint(3, 7))):
+            d = big_data(rs)
+            co = zlib.compressobj(int(rs.choice([0, 1, 3, 6])), zlib.DEFLATED, WBITS[fmt])
+            parts, at = [], 0
+            while at < len(d):
+                step = int(rs.choice([3000, 40000, 200000, 900000]) * rs.uniform(0.3, 1.0))
+                parts.append(co.compress(d[at:at + step]))
+                at += step
+                kind = rs.randint(0, 5)
+                if kind < 4:
+                    parts.append(co.flush([zlib.Z_SYNC_FLUSH, zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK][kind]))
+            parts.append(co.flush())
+            s = b"".join(parts)
+            streams.append(s)
+            caps.append(len(d) - int(rs.choice([0, 0, 0, 1, 70000])))
+            b = bytearray(s)
+            what = rs.randint(0, 3)
+            if what == 0:
+                b[rs.randint(0, len(b))] ^= 1 << rs.randint(0, 8)
+            elif what == 1:
+                b = b[:rs.randint(len(b) // 2, len(b))]
+            else:
+                at = rs.randint(len(b) // 2, len(b))
+                b[at:at + 64] = rs.randint(0, 256, size=len(b[at:at + 64]), dtype=np.uint8).tobytes()
+            streams.append(bytes(b))
+            caps.append(len(d))
+        if rs.randint(0, 2):
+            comp, st = eng.batch_compress([big_data(rs) for _ in range(2)], fmt, int(rs.choice([1, 6])))
+            for c in comp:
+                streams.append(c)
+                caps.append(6 << 20)
+        caps = [max(0, c) for c in caps]
+        got, status = eng.batch_decompress(streams, caps, fmt)
+        cut += eng.last_parts() > len(streams)
+        for i, s in enumerate(streams):
+            r, _, want = o.decompress(s, caps[i], fmt)
+            if int(status[i]) != r or (r == o.SUCCESS and got[i] != want):
+                if fmt != 0 and trailer_is_displaced(s, fmt):
+                    continue
+                print("MISMATCH seed %d item %d fmt %d: gpu %d oracle %d" % (seed, i, fmt, int(status[i]), r))
+                with open("gpurun_out/fuzz_pfail_%d_%d.bin" % (seed, i), "wb") as f:
+                    f.write(s)
+                sys.exit(1)
+        total += len(streams)
+        print("seed %d ok (%d streams, fmt %d, %d parts, %d whole)" % (seed, len(streams), fmt, eng.last_parts(),
+                                                                      eng.last_whole()), flush=True)
+        seed += 1
+    print("parts fuzz ok: %d streams, seeds up to %d, %d batches cut" % (total, seed - 1, cut))
 
 
 def fuzz_inflate(eng, budget, seed, max_seeds=1 << 30):
