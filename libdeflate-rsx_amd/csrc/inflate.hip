@@ -150,8 +150,6 @@ __constant__ uint16_t c_off_base[32] = {1,    2,    3,    4,    5,    7,     9, 
                                         4097, 6145, 8193, 12289, 16385, 24577, 24577, 24577};
 __constant__ uint8_t c_off_extra[32] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,  4,  5,  5,  6,  6,
                                         7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 13, 13};
-__constant__ uint8_t c_precode_perm[19] = {16, 17, 18, 0, 8,  7, 9,  6, 10, 5,
-                                           11, 4,  12, 3, 13, 2, 14, 1, 15};
 
 // per-symbol decode results, src/decompress/tables.rs:10-30, :55-379; `len` = codeword bits
 // this entry accounts for, `root_bits` = index width of the litlen root table
@@ -178,10 +176,9 @@ struct HeaderScratch {
     uint32_t precode[kPrecodeEnough];
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
-    uint8_t precode_lens[20];
     uint32_t num_litlen, num_offset;   // alphabet sizes of the block whose tables are being built
     uint32_t len_counts[16], offsets[16];   // working arrays of the table build
-    uint32_t plan;                     // 0 nothing to build, 1 the static code, 2 lens[] of a dynamic header
+    uint32_t plan;                     // 0 nothing to build, 1 the static code, 3 a dynamic header whose counts start at `after`
     uint32_t after;                    // window bit position behind the header
 };
 struct SpecScratch {
@@ -239,73 +236,6 @@ struct __align__(16) StreamLdsT {
 typedef StreamLdsT<kWinBytes, kRing> StreamLds;   // the one-kernel decoder's
 #define RSX_LDS __attribute__((address_space(3)))
 typedef RSX_LDS StreamLds LdsStream;
-
-// Serial decode-table build for the precode (19 symbols, codewords of at most 7 bits = the
-// table index, so no subtables); restates src/decompress/mod.rs:1324-1495 for that case (called
-// by one thread).  Returns false when the code-length set is rejected.  len_counts and offsets
-// are 16 words of scratch each.
-__device__ __noinline__ bool build_precode_table(RSX_LDS uint32_t *table, const RSX_LDS uint8_t *lens,
-                                                 RSX_LDS uint16_t *sorted_syms, RSX_LDS uint32_t *len_counts,
-                                                 RSX_LDS uint32_t *offsets)
-{
-    const uint32_t num_syms = 19, table_bits = kPrecodeBits;
-    uint32_t max_codeword_len = 7;
-    for (int i = 0; i < 16; i++) len_counts[i] = 0;
-    for (uint32_t s = 0; s < num_syms; s++) len_counts[lens[s]]++;
-    while (max_codeword_len > 1 && len_counts[max_codeword_len] == 0) max_codeword_len--;
-    offsets[0] = 0;
-    offsets[1] = len_counts[0];
-    uint32_t codespace_used = 0;
-    for (uint32_t len = 1; len < max_codeword_len; len++) {
-        offsets[len + 1] = offsets[len] + len_counts[len];
-        codespace_used = (codespace_used << 1) + len_counts[len];
-    }
-    codespace_used = (codespace_used << 1) + len_counts[max_codeword_len];
-    for (uint32_t s = 0; s < num_syms; s++) sorted_syms[offsets[lens[s]]++] = (uint16_t)s;
-
-    if (codespace_used > (1u << max_codeword_len)) return false;
-    if (codespace_used < (1u << max_codeword_len)) {
-        uint32_t s;
-        if (codespace_used == 0) {
-            s = 0;
-        } else {
-            if (codespace_used != (1u << (max_codeword_len - 1)) || len_counts[1] != 1) return false;
-            s = sorted_syms[offsets[0]];
-        }
-        uint32_t e = make_precode_entry(s, 1);
-        for (uint32_t i = 0; i < (1u << table_bits); i++) table[i] = e;
-        return true;
-    }
-
-    const RSX_LDS uint16_t *sp = sorted_syms + offsets[0];
-    uint32_t codeword = 0;
-    uint32_t len = 1;
-    while (len_counts[len] == 0) len++;
-    uint32_t cur_table_end = 1u << len;
-    while (len <= table_bits) {
-        uint32_t count = len_counts[len];
-        while (count--) {
-            table[codeword] = make_precode_entry(*sp++, len);
-            if (codeword == cur_table_end - 1) {
-                for (; len < table_bits; len++) {
-                    for (uint32_t i = 0; i < cur_table_end; i++) table[cur_table_end + i] = table[i];
-                    cur_table_end <<= 1;
-                }
-                return true;
-            }
-            uint32_t bit = 1u << (31 - __clz(codeword ^ (cur_table_end - 1)));
-            codeword &= bit - 1;
-            codeword |= bit;
-        }
-        do {
-            if (++len <= table_bits) {
-                for (uint32_t i = 0; i < cur_table_end; i++) table[cur_table_end + i] = table[i];
-                cur_table_end <<= 1;
-            }
-        } while (len <= table_bits && len_counts[len] == 0);
-    }
-    return false;   // not reached: a complete code ends on the all-ones codeword above
-}
 
 // Orders the LDS traffic of one wave: its lanes run in step and the LDS serves a wave's
 // requests in order, so this only has to keep the compiler from moving accesses across.
@@ -517,72 +447,160 @@ __device__ inline void stage_window(LS &L, const StreamCtx &c, int64_t *win_bit0
     if (threadIdx.x < 4) L.win[kWinWords + threadIdx.x] = 0;
 }
 
-// Read the 14-bit dynamic header + code lengths (src/decompress/mod.rs:403-507) into
-// L.hdr.lens and leave the two alphabet sizes in L.hdr.num_litlen / num_offset; the big
-// tables are built afterwards by the whole wave.  Runs on one thread; reads bits through the
-// staged window, which the caller guarantees covers the whole header
-// (a header is at most 14 + 19*3 + 320*(7+7) bits < 600 bytes).
+// The 14-bit dynamic header + code lengths (src/decompress/mod.rs:403-507) go into L.hdr.lens, the two
+// alphabet sizes into L.hdr.num_litlen / num_offset; the big tables are built afterwards by the whole
+// wave.  Bits are read through the staged window, which the caller guarantees covers the whole header
+// (a header is at most 14 + 19*3 + 320*(7+7) bits < 600 bytes) and 40 bytes behind it.
 struct HeaderResult {
     int code;      // DecompressResult
     uint32_t b;    // window bit position behind the header (by value: no pointer into the caller's stack)
 };
+// A dynamic header (src/decompress/mod.rs:403-478) is read by the first wave, every lane taking part and
+// every value that decides control flow uniform.  First the three counts and the code lengths of the
+// precode, then the precode's decode table (src/decompress/mod.rs:1324-1495 for 19 symbols and codewords of
+// at most 7 bits = the table index, so no subtables; same checks, same entries): lane s holds the length of
+// symbol s and works out its canonical codeword from the ballots of the seven lengths, lanes t and t + 64
+// pick the symbol whose bit-reversed codeword ends table indices t and t + 64.
 template <class LS>
-__device__ __noinline__ HeaderResult read_dynamic_header(LS &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
+__device__ __noinline__ HeaderResult read_dynamic_preamble_wave(LS &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
 {
-    auto avail = [&](uint32_t need) { return (uint64_t)(win_bit0 + b + need) <= end_bit; };
-    if (!avail(14)) return HeaderResult{RSX_SHORT_INPUT, b};
-    uint32_t bits = fetch_bits(L.win, b);
-    uint32_t num_litlen = 257 + (bits & 0x1F);
-    uint32_t num_offset = 1 + ((bits >> 5) & 0x1F);
-    uint32_t num_precode = 4 + ((bits >> 10) & 0xF);
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1;
+    b = __builtin_amdgcn_readfirstlane(b);
+    const uint64_t left = end_bit - (uint64_t)win_bit0;   // (the window never starts behind the end)
+    const uint32_t end_b = __builtin_amdgcn_readfirstlane(left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left);
+    if (b + 14 > end_b) return HeaderResult{RSX_SHORT_INPUT, b};
+    const uint32_t bits = __builtin_amdgcn_readfirstlane(fetch_bits(L.win, b));
+    const uint32_t num_litlen = 257 + (bits & 0x1F);
+    const uint32_t num_offset = 1 + ((bits >> 5) & 0x1F);
+    const uint32_t num_precode = 4 + ((bits >> 10) & 0xF);
     b += 14;
-    uint32_t i;
-    for (i = 0; i < num_precode; i++) {
-        if (!avail(3)) return HeaderResult{RSX_SHORT_INPUT, b};
-        L.hdr.precode_lens[c_precode_perm[i]] = fetch_bits(L.win, b) & 7;
-        b += 3;
+    if (b + 3 * num_precode > end_b) return HeaderResult{RSX_SHORT_INPUT, b};
+    // field i is the length of symbol perm[i] (RFC 1951 3.2.7); lane s takes field inv[s], 5 bits each
+    // inv = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2}
+    constexpr unsigned long long kInvLo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 |
+                                          7ull << 30 | 5ull << 35 | 4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;
+    constexpr unsigned long long kInvHi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;
+    const uint32_t field = lane < 12 ? (uint32_t)(kInvLo >> (5 * lane)) & 31 : lane < 19 ? (uint32_t)(kInvHi >> (5 * (lane - 12))) & 31 : 31u;
+    uint32_t mylen = 0;
+    if (field < num_precode) mylen = fetch_bits(L.win, b + 3 * field) & 7;
+    b += 3 * num_precode;
+
+    uint32_t cnt[8], max_len = 1, rank = 0;
+#pragma unroll
+    for (uint32_t len = 1; len <= 7; len++) {
+        const unsigned long long m = __ballot(mylen == len);
+        cnt[len] = (uint32_t)__popcll(m);
+        if (mylen == len) rank = (uint32_t)__popcll(m & below);
+        if (cnt[len]) max_len = len;
     }
-    for (; i < 19; i++) L.hdr.precode_lens[c_precode_perm[i]] = 0;
-    if (!build_precode_table(L.hdr.precode, L.hdr.precode_lens, L.hdr.sorted_syms, L.hdr.len_counts,
-                             L.hdr.offsets))
-        return HeaderResult{RSX_BAD_DATA, b};
-    const uint32_t total = num_litlen + num_offset;
-    i = 0;
+    uint32_t codespace_used = 0, first_code[8], code = 0;
+#pragma unroll
+    for (uint32_t len = 1; len <= 7; len++) {
+        if (len <= max_len) codespace_used = (codespace_used << 1) + cnt[len];
+        first_code[len] = code;
+        code = (code + cnt[len]) << 1;
+    }
+    if (codespace_used > (1u << max_len)) return HeaderResult{RSX_BAD_DATA, b};
+    uint32_t e0, e1;
+    if (codespace_used < (1u << max_len)) {
+        uint32_t sym = 0;
+        if (codespace_used != 0) {
+            if (codespace_used != (1u << (max_len - 1)) || cnt[1] != 1) return HeaderResult{RSX_BAD_DATA, b};
+            sym = (uint32_t)__ffsll((long long)__ballot(mylen == 1)) - 1;   // the only symbol with a codeword
+        }
+        e0 = e1 = make_precode_entry(sym, 1);
+    } else {
+        uint32_t mycode = 0;
+#pragma unroll
+        for (uint32_t len = 1; len <= 7; len++)
+            if (mylen == len) mycode = first_code[len] + rank;
+        const uint32_t rev = mylen ? __brev(mycode) >> (32 - mylen) : 0u;
+        const uint32_t word = mylen | rev << 8;
+        e0 = e1 = 0;
+        for (uint32_t sym = 0; sym < 19; sym++) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)sym);
+            const uint32_t len = w & 0xFF, mask = (1u << len) - 1;
+            if (len == 0) continue;   // (uniform)
+            if ((lane & mask) == w >> 8) e0 = make_precode_entry(sym, len);
+            if (((lane + 64) & mask) == w >> 8) e1 = make_precode_entry(sym, len);
+        }
+    }
+    L.hdr.precode[lane] = e0;
+    L.hdr.precode[lane + 64] = e1;
+    if (lane == 0) {
+        L.hdr.num_litlen = num_litlen;
+        L.hdr.num_offset = num_offset;
+    }
+    WAVE_SYNC();
+    return HeaderResult{RSX_SUCCESS, b};
+}
+
+// The code lengths of a dynamic header (src/decompress/mod.rs:436-478), read by one wave in step.  The
+// tokens of the precode are still taken one after the other, with the reference's checks in the reference's
+// order, but nothing on that path waits for the LDS: lane k looks up the token that would start k bits
+// behind `b` (four registers of 64 positions each), and the walk from token to token reads those lanes
+// (the lane index is uniform, so the walk runs on the scalar unit); a run is written by as many lanes as
+// it is long.  Every value that decides control flow is uniform in the wave.
+template <class LS>
+__device__ __noinline__ HeaderResult read_code_lengths_wave(LS &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
+{
+    constexpr uint32_t kSpan = 4;   // registers of 64 positions per refill
+    const uint32_t lane = threadIdx.x & 63;
+    // (told to the compiler as uniform, so that the walk stays in scalar registers)
+    const uint32_t total = __builtin_amdgcn_readfirstlane(L.hdr.num_litlen + L.hdr.num_offset);
+    b = __builtin_amdgcn_readfirstlane(b);
+    // window bit position of the end of the input, as far as 32 bits hold it
+    const uint64_t left = end_bit - (uint64_t)win_bit0;   // (the window never starts behind the end)
+    const uint32_t end_b = __builtin_amdgcn_readfirstlane(left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left);
+    uint32_t i = 0, last_val = 0;
     while (i < total) {
-        bits = fetch_bits(L.win, b);
-        uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
-        uint32_t nbits = e & 0xFF;
-        if (!avail(nbits)) return HeaderResult{RSX_SHORT_INPUT, b};
-        b += nbits;
-        bits >>= nbits;
-        uint32_t presym = e >> 16;
-        if (presym < 16) {
-            L.hdr.lens[i++] = (uint8_t)presym;
-            continue;
+        // packed: codeword bits | extra bits << 4 | symbol << 8 | value of the extra bits << 16
+        uint32_t packed[kSpan];
+#pragma unroll
+        for (uint32_t k = 0; k < kSpan; k++) {
+            const uint32_t bits = fetch_bits(L.win, b + k * 64 + lane);
+            const uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
+            const uint32_t nb = e & 0xFF, sym = e >> 16;
+            const uint32_t xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+            packed[k] = nb | xb << 4 | sym << 8 | ((bits >> nb) & ((1u << xb) - 1)) << 16;
         }
-        uint32_t rep, val, xb;
-        if (presym == 16) {
-            if (i == 0) return HeaderResult{RSX_BAD_DATA, b};
-            val = L.hdr.lens[i - 1];
-            xb = 2;
-            rep = 3;
-        } else if (presym == 17) {
-            val = 0;
-            xb = 3;
-            rep = 3;
-        } else {
-            val = 0;
-            xb = 7;
-            rep = 11;
+        uint32_t q = 0;   // the next token starts q bits behind b (uniform)
+        while (q < kSpan * 64 && i < total) {
+            uint32_t t = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kSpan; k++)
+                if (q >> 6 == k) t = (uint32_t)__builtin_amdgcn_readlane((int)packed[k], (int)(q & 63));
+            const uint32_t nb = t & 15, xb = (t >> 4) & 15, sym = (t >> 8) & 0xFF, xv = t >> 16;
+            if (b + q + nb > end_b) return HeaderResult{RSX_SHORT_INPUT, b + q};
+            q += nb;
+            if (sym < 16) {
+                if (lane == 0) L.hdr.lens[i] = (uint8_t)sym;
+                last_val = sym;
+                i++;
+                continue;
+            }
+            uint32_t rep, val;
+            if (sym == 16) {
+                if (i == 0) return HeaderResult{RSX_BAD_DATA, b + q};
+                val = last_val;
+                rep = 3;
+            } else {
+                val = 0;
+                rep = sym == 17 ? 3 : 11;
+            }
+            if (b + q + xb > end_b) return HeaderResult{RSX_SHORT_INPUT, b + q};
+            rep += xv;
+            q += xb;
+            // a run passing the end is clamped (src/decompress/mod.rs:462-467)
+            if (rep > total - i) rep = total - i;
+            for (uint32_t k = lane; k < rep; k += 64) L.hdr.lens[i + k] = (uint8_t)val;
+            last_val = val;
+            i += rep;
         }
-        if (!avail(xb)) return HeaderResult{RSX_SHORT_INPUT, b};
-        rep += bits & ((1u << xb) - 1);
-        b += xb;
-        // a run passing the end is clamped (src/decompress/mod.rs:462-467)
-        while (rep-- && i < total) L.hdr.lens[i++] = (uint8_t)val;
+        b += q;
     }
-    L.hdr.num_litlen = num_litlen;
-    L.hdr.num_offset = num_offset;
+    WAVE_SYNC();
     return HeaderResult{RSX_SUCCESS, b};
 }
 
@@ -642,13 +660,7 @@ __device__ __noinline__ void parse_block_header(LS &L, const StreamCtx &c, int64
         return;
     }
     if (type == 2) {
-        const HeaderResult r = read_dynamic_header(L, b, win_bit0, end_bit);
-        if (r.code != RSX_SUCCESS) {
-            L.status = r.code;
-            return;
-        }
-        b = r.b;
-        L.hdr.plan = 2;
+        L.hdr.plan = 3;   // the wave reads the rest of the header
     } else {
         L.hdr.plan = 1;
     }
@@ -661,13 +673,23 @@ __device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_
     unsigned long long th0 = SPLIT_T_NOW();
     if (threadIdx.x == 0) parse_block_header(L, c, win_bit0);
     WAVE_SYNC();
-    if (RSX_SPLIT_TIMERS && threadIdx.x == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(13, t - th0); th0 = t; }
     const uint32_t plan = L.hdr.plan;   // (uniform)
     if (plan == 0) return;
     if (plan == 1) {
         load_static_lens(L);
         WAVE_SYNC();
     }
+    if (plan == 3) {
+        HeaderResult r = read_dynamic_preamble_wave(L, L.hdr.after, win_bit0, c.body_len * 8);
+        if (r.code == RSX_SUCCESS) r = read_code_lengths_wave(L, r.b, win_bit0, c.body_len * 8);
+        WAVE_SYNC();   // (everyone has read hdr.after)
+        if (r.code != RSX_SUCCESS) {   // (uniform)
+            if (threadIdx.x == 0) L.status = r.code;
+            return;
+        }
+        if (threadIdx.x == 0) L.hdr.after = r.b;
+    }
+    if (RSX_SPLIT_TIMERS && threadIdx.x == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(13, t - th0); th0 = t; }
     const uint32_t num_litlen = L.hdr.num_litlen, num_offset = L.hdr.num_offset;
     // the litlen table first: the offset entries carry the index width of its root
     bool ok = build_decode_table_wave(L.tab + kTabLitlen, kTabLitlen, L.hdr.lens, num_litlen, KIND_LITLEN,
