@@ -139,17 +139,39 @@ static_assert(4 * kTabLitlen == kEntNextLit, "the flag is the table's byte offse
 
 enum { KIND_LITLEN = 1, KIND_OFFSET = 2 };
 
-__constant__ uint16_t c_len_base[31] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,
-                                        17, 19, 23, 27, 31, 35, 43, 51, 59,  67,  83,
-                                        99, 115, 131, 163, 195, 227, 258, 258, 258};
-__constant__ uint8_t c_len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
-                                        3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
-__constant__ uint16_t c_off_base[32] = {1,    2,    3,    4,    5,    7,     9,     13,
-                                        17,   25,   33,   49,   65,   97,    129,   193,
-                                        257,  385,  513,  769,  1025, 1537,  2049,  3073,
-                                        4097, 6145, 8193, 12289, 16385, 24577, 24577, 24577};
-__constant__ uint8_t c_off_extra[32] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,  4,  5,  5,  6,  6,
-                                        7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 13, 13};
+// Base values and extra-bit counts of the length symbols 257.. and of the offset symbols (RFC 1951 3.2.5;
+// the symbols that no valid stream uses decode like the reference's tables say).  They are computed, not
+// loaded: a table in constant memory costs the table build one memory latency per codeword length.
+constexpr uint16_t kLenBase[31] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,
+                                   17, 19, 23, 27, 31, 35, 43, 51, 59,  67,  83,
+                                   99, 115, 131, 163, 195, 227, 258, 258, 258};
+constexpr uint8_t kLenExtra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+                                   3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
+constexpr uint16_t kOffBase[32] = {1,    2,    3,    4,    5,    7,     9,     13,
+                                   17,   25,   33,   49,   65,   97,    129,   193,
+                                   257,  385,  513,  769,  1025, 1537,  2049,  3073,
+                                   4097, 6145, 8193, 12289, 16385, 24577, 24577, 24577};
+constexpr uint8_t kOffExtra[32] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,  4,  5,  5,  6,  6,
+                                   7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 13, 13};
+__host__ __device__ constexpr uint32_t len_extra(uint32_t i) { return i < 8 || i >= 28 ? 0u : (i - 4) >> 2; }
+__host__ __device__ constexpr uint32_t len_base(uint32_t i)
+{
+    return i >= 28 ? 258u : i < 8 ? 3 + i : 3 + ((4 + (i & 3)) << len_extra(i));
+}
+__host__ __device__ constexpr uint32_t off_extra(uint32_t s) { return s < 4 ? 0u : ((s < 29 ? s : 29u) - 2) >> 1; }
+__host__ __device__ constexpr uint32_t off_base(uint32_t s)
+{
+    return s < 4 ? 1 + s : 1 + ((2 + ((s < 29 ? s : 29u) & 1)) << off_extra(s));
+}
+constexpr bool symbol_formulas_match_tables()
+{
+    for (uint32_t i = 0; i < 31; i++)
+        if (len_base(i) != kLenBase[i] || len_extra(i) != kLenExtra[i]) return false;
+    for (uint32_t s = 0; s < 32; s++)
+        if (off_base(s) != kOffBase[s] || off_extra(s) != kOffExtra[s]) return false;
+    return true;
+}
+static_assert(symbol_formulas_match_tables(), "the formulas give the tables' values");
 
 // per-symbol decode results, src/decompress/tables.rs:10-30, :55-379; `len` = codeword bits
 // this entry accounts for, `root_bits` = index width of the litlen root table
@@ -160,10 +182,10 @@ __device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t len, uint
         if (sym < 256) return (sym << 16) | (kTokLit << 9) | back | (len << 5) | len;
         if (sym == 256) return (kTokEob << 9) | back | (len << 5) | len;
         // a length: its distance comes from the offset root
-        return ((uint32_t)c_len_base[sym - 257] << 16) | (kTokNone << 9) | ((uint32_t)kOffsetBits << 12) | (len << 5) |
-               (len + c_len_extra[sym - 257]);
+        return (len_base(sym - 257) << 16) | (kTokNone << 9) | ((uint32_t)kOffsetBits << 12) | (len << 5) |
+               (len + len_extra(sym - 257));
     }
-    return ((uint32_t)c_off_base[sym] << 16) | (kTokMatch << 9) | back | (len << 5) | (len + c_off_extra[sym]);
+    return (off_base(sym) << 16) | (kTokMatch << 9) | back | (len << 5) | (len + off_extra(sym));
 }
 
 // the precode's entries: symbol << 16 | codeword length
@@ -244,9 +266,12 @@ typedef RSX_LDS StreamLds LdsStream;
 // The litlen or offset table (src/decompress/mod.rs:1324-1495: same checks, same root and
 // subtable layout, the entries in this file's format) built by the 64 lanes of one wave.
 // Everything that decides the layout -- code-space checks, the canonical first codeword of
-// each length, the sizes and places of the subtables -- is computed alike by every lane; the
-// lanes share the counting, the sorting of the symbols, the placing of the codewords of one
-// length and the doubling of the table between lengths.  `table_index` is where table[0] sits
+// each length, the sizes and places of the subtables -- is uniform in the wave and kept in scalar
+// registers: the counts of the sixteen lengths and the running starts of their symbols sit in lanes 0..15
+// of two vector registers and are read and written by lane number, so the serial parts of the build wait
+// for no LDS round trip.  The lanes share the counting, the sorting of the symbols and the filling: the
+// codewords of one length fill all their root entries at once (lanes split into symbol x replica), a
+// subtable entry is replicated by the lanes.  `table_index` is where table[0] sits
 // in the decoder's table space (subtable pointers are absolute byte offsets); `root_bits` the index width of
 // the litlen root, for the entries that lead back to it (ignored when table_bits_ret is given:
 // then this IS the litlen table and its own shrunk width is used and returned).
@@ -259,44 +284,57 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, ui
 {
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1;
+    num_syms = __builtin_amdgcn_readfirstlane(num_syms);
+    table_bits = __builtin_amdgcn_readfirstlane(table_bits);
+    max_codeword_len = __builtin_amdgcn_readfirstlane(max_codeword_len);   // (at most 15)
+    root_bits = __builtin_amdgcn_readfirstlane(root_bits);
     if (lane < 16) len_counts[lane] = 0;
     WAVE_SYNC();
     for (uint32_t s = lane; s < num_syms; s += 64)
         __hip_atomic_fetch_add(&len_counts[lens[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     WAVE_SYNC();
-    while (max_codeword_len > 1 && len_counts[max_codeword_len] == 0) max_codeword_len--;
+    // lane l < 16 holds the count of length l
+    const uint32_t cntv = lane < 16 ? len_counts[lane] : 0u;
+    auto cnt = [&](uint32_t len) { return (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)len); };
+    while (max_codeword_len > 1 && cnt(max_codeword_len) == 0) max_codeword_len--;
     if (table_bits_ret) {
         if (table_bits > max_codeword_len) table_bits = max_codeword_len;
         if (lane == 0) *table_bits_ret = table_bits;
         root_bits = table_bits;
     }
-    // offsets[len] = where the symbols of that length start in sorted_syms
-    uint32_t codespace_used = 0;
+    // lane l < 16 of startv: where the symbols of length l start in sorted_syms; of runv: the same, advanced
+    // by the sort
+    uint32_t startv = 0, codespace_used = 0;
     {
         uint32_t at = 0;
         for (uint32_t len = 0; len <= max_codeword_len; len++) {
-            if (lane == 0) offsets[len] = at;
-            at += len_counts[len];
-            if (len >= 1) codespace_used = (codespace_used << 1) + len_counts[len];
+            startv = lane == len ? at : startv;
+            const uint32_t c = cnt(len);
+            at += c;
+            if (len >= 1) codespace_used = (codespace_used << 1) + c;
+        }
+    }
+    auto start = [&](uint32_t len) { return (uint32_t)__builtin_amdgcn_readlane((int)startv, (int)len); };
+    // stable counting sort, 64 symbols at a time: a lane's place is the running start of its
+    // length plus the number of lower lanes with the same length
+    {
+        uint32_t runv = startv;
+        for (uint32_t base = 0; base < num_syms; base += 64) {
+            const uint32_t s = base + lane;
+            const uint32_t mylen = s < num_syms ? lens[s] : 0xFFu;
+            for (uint32_t len = 0; len <= max_codeword_len; len++) {
+                const unsigned long long same = __ballot(mylen == len);
+                if (same) {   // (uniform)
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)runv, (int)len);
+                    if (mylen == len) sorted_syms[o + (uint32_t)__popcll(same & below)] = (uint16_t)s;
+                    runv = lane == len ? o + (uint32_t)__popcll(same) : runv;
+                }
+            }
         }
     }
     WAVE_SYNC();
-    // stable counting sort, 64 symbols at a time: a lane's place is the running start of its
-    // length plus the number of lower lanes with the same length
-    for (uint32_t base = 0; base < num_syms; base += 64) {
-        const uint32_t s = base + lane;
-        const uint32_t mylen = s < num_syms ? lens[s] : 0xFFu;
-        for (uint32_t len = 0; len <= max_codeword_len; len++) {
-            const unsigned long long same = __ballot(mylen == len);
-            if (same) {   // (uniform)
-                const uint32_t o = offsets[len];
-                if (mylen == len) sorted_syms[o + (uint32_t)__popcll(same & below)] = (uint16_t)s;
-                if (lane == 0) offsets[len] = o + (uint32_t)__popcll(same);
-            }
-        }
-        WAVE_SYNC();
-    }
-    // now offsets[len] = end of the symbols of that length
+    const uint32_t first_sym = cnt(0);     // index into sorted_syms of the first symbol with a codeword
+    const uint32_t end_sym = num_syms;     // and behind the last one
 
     if (codespace_used > (1u << max_codeword_len)) return false;
     if (codespace_used < (1u << max_codeword_len)) {
@@ -304,8 +342,8 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, ui
         if (codespace_used == 0) {
             s = 0;
         } else {
-            if (codespace_used != (1u << (max_codeword_len - 1)) || len_counts[1] != 1) return false;
-            s = sorted_syms[offsets[0]];
+            if (codespace_used != (1u << (max_codeword_len - 1)) || cnt(1) != 1) return false;
+            s = sorted_syms[first_sym];
         }
         const uint32_t e = make_entry(kind, s, 1, root_bits);
         for (uint32_t i = lane; i < (1u << table_bits); i += 64) table[i] = e;
@@ -313,34 +351,33 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, ui
         return true;
     }
 
-    // root table, one codeword length after the other: double what is there, then place the
-    // codewords of this length (canonical codeword number, bit-reversed, is the table index)
-    uint32_t len = 1;
-    while (len_counts[len] == 0) len++;
+    // root table: the codewords of one length fill all their entries at once (canonical codeword number,
+    // bit-reversed, is the low end of the table index; every value of the bits above it is a replica).
+    // The lanes are split into (symbol, replica): a power of two of symbols side by side.
     uint32_t first_code = 0;             // canonical (MSB-first) first codeword of `len`
-    uint32_t sp = offsets[0];            // index into sorted_syms of the first symbol of `len`
-    bool grown = false;
+    uint32_t len = 1;
     for (; len <= table_bits; len++) {
-        const uint32_t count = len_counts[len];
-        if (grown) {
-            const uint32_t half = 1u << (len - 1);
-            for (uint32_t i = lane; i < half; i += 64) table[half + i] = table[i];
-            WAVE_SYNC();
+        const uint32_t count = cnt(len);
+        if (count) {   // (uniform)
+            const uint32_t sh = count >= 64 ? 6u : 32u - (uint32_t)__clz((int)(count - 1));   // log2 of the symbols side by side (count 1: 0)
+            const uint32_t reps = 1u << (table_bits - len);
+            const uint32_t sp = start(len);
+            for (uint32_t j = lane & ((1u << sh) - 1); j < count; j += 1u << sh) {
+                const uint32_t rev = __brev(first_code + j) >> (32 - len);
+                const uint32_t e = make_entry(kind, sorted_syms[sp + j], len, root_bits);
+                for (uint32_t rep = lane >> sh; rep < reps; rep += 64u >> sh) table[rev | rep << len] = e;
+            }
         }
-        grown = true;
-        for (uint32_t j = lane; j < count; j += 64) {
-            const uint32_t rev = __brev(first_code + j) >> (32 - len);
-            table[rev] = make_entry(kind, sorted_syms[sp + j], len, root_bits);
-        }
-        WAVE_SYNC();
-        sp += count;
         first_code = (first_code + count) << 1;
     }
-    if (sp >= offsets[max_codeword_len]) return true;   // no codeword is longer than the root index
+    if (max_codeword_len <= table_bits) {   // no codeword is longer than the root index
+        WAVE_SYNC();
+        return true;
+    }
 
     // subtables (codewords longer than table_bits), in canonical order as the serial build;
     // `len` is the first length behind the root, first_code its first codeword
-    while (len_counts[len] == 0) {
+    while (cnt(len) == 0) {
         len++;
         first_code <<= 1;
     }
@@ -348,36 +385,45 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, ui
     uint32_t cur_table_end = 1u << table_bits;
     uint32_t subtable_prefix = ~0u;
     uint32_t subtable_start = 0;
-    for (;;) {
-        if ((codeword & ((1u << table_bits) - 1)) != subtable_prefix) {
-            subtable_prefix = codeword & ((1u << table_bits) - 1);
-            subtable_start = cur_table_end;
-            uint32_t subtable_bits = len - table_bits;
-            uint32_t sub_used = len_counts[len];
-            while (sub_used < (1u << subtable_bits)) {
-                subtable_bits++;
-                sub_used = (sub_used << 1) +
-                           (table_bits + subtable_bits <= 15 ? len_counts[table_bits + subtable_bits] : 0);
+    uint32_t sp = start(len);
+    bool last = false;
+    for (; len <= max_codeword_len && !last; len++) {
+        const uint32_t count = cnt(len);
+        for (uint32_t j0 = 0; j0 < count && !last; j0 += 64) {
+            // the symbols of up to 64 codewords in one read; the walk takes them by lane number
+            const uint32_t symv = sp + j0 + lane < end_sym ? (uint32_t)sorted_syms[sp + j0 + lane] : 0u;
+            const uint32_t j1 = count - j0 < 64 ? count - j0 : 64;
+            for (uint32_t j = 0; j < j1; j++) {
+                if ((codeword & ((1u << table_bits) - 1)) != subtable_prefix) {
+                    subtable_prefix = codeword & ((1u << table_bits) - 1);
+                    subtable_start = cur_table_end;
+                    uint32_t subtable_bits = len - table_bits;
+                    uint32_t sub_used = count - j0 - j;   // codewords of this length that are left
+                    while (sub_used < (1u << subtable_bits)) {
+                        subtable_bits++;
+                        sub_used = (sub_used << 1) + (table_bits + subtable_bits <= 15 ? cnt(table_bits + subtable_bits) : 0);
+                    }
+                    cur_table_end = subtable_start + (1u << subtable_bits);
+                    if (lane == 0)
+                        table[subtable_prefix] = kEntPointer | (4 * (table_index + subtable_start) << 16) |
+                                                 (subtable_bits << 12) | (table_bits << 5) | table_bits;
+                }
+                const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)symv, (int)j);
+                const uint32_t e = make_entry(kind, sym, len - table_bits, root_bits);
+                const uint32_t stride = 1u << (len - table_bits);
+                for (uint32_t i = subtable_start + (codeword >> table_bits) + lane * stride; i < cur_table_end;
+                     i += 64 * stride)
+                    table[i] = e;
+                if (codeword == (1u << len) - 1) {   // the last codeword of a complete code
+                    last = true;
+                    break;
+                }
+                const uint32_t bit = 1u << (31 - __clz(codeword ^ ((1u << len) - 1)));
+                codeword &= bit - 1;
+                codeword |= bit;
             }
-            cur_table_end = subtable_start + (1u << subtable_bits);
-            if (lane == 0)
-                table[subtable_prefix] = kEntPointer | (4 * (table_index + subtable_start) << 16) |
-                                         (subtable_bits << 12) | (table_bits << 5) | table_bits;
         }
-        const uint32_t e = make_entry(kind, sorted_syms[sp++], len - table_bits, root_bits);
-        const uint32_t stride = 1u << (len - table_bits);
-        for (uint32_t i = subtable_start + (codeword >> table_bits) + lane * stride; i < cur_table_end;
-             i += 64 * stride)
-            table[i] = e;
-        if (codeword == (1u << len) - 1) break;
-        const uint32_t bit = 1u << (31 - __clz(codeword ^ ((1u << len) - 1)));
-        codeword &= bit - 1;
-        codeword |= bit;
-        const uint32_t left = len_counts[len] - 1;
-        WAVE_SYNC();                        // every lane has read the count before it changes
-        if (lane == 0) len_counts[len] = left;
-        WAVE_SYNC();
-        while (len_counts[len] == 0) len++;
+        sp += count;
     }
     WAVE_SYNC();
     return true;
@@ -536,72 +582,135 @@ __device__ __noinline__ HeaderResult read_dynamic_preamble_wave(LS &L, uint32_t 
     return HeaderResult{RSX_SUCCESS, b};
 }
 
-// The code lengths of a dynamic header (src/decompress/mod.rs:436-478), read by one wave in step.  The
-// tokens of the precode are still taken one after the other, with the reference's checks in the reference's
-// order, but nothing on that path waits for the LDS: lane k looks up the token that would start k bits
-// behind `b` (four registers of 64 positions each), and the walk from token to token reads those lanes
-// (the lane index is uniform, so the walk runs on the scalar unit); a run is written by as many lanes as
-// it is long.  Every value that decides control flow is uniform in the wave.
+// The code lengths of a dynamic header (src/decompress/mod.rs:436-478), read by one wave.  A wave that walks
+// the tokens of the precode one after the other is bound by how fast one wave can issue instructions (a
+// few hundred cycles per token when the other waves of the CU are busy), so the tokens are decoded side by
+// side instead: lane k takes the tokens that start in bits [32k, 32k + 32) behind `b`.  Where its first
+// token starts is where lane k - 1 stopped; lanes guess, decode, hand their exits on and decode again
+// until nothing changes (a Huffman decoder that starts at a wrong bit falls into step with the right one
+// after a few tokens, so two or three passes do).  Then a prefix sum over the lanes' run totals tells
+// every lane where its first length goes, and a last pass writes them.  Only non-zero lengths are
+// written (the array is cleared first), so no run is longer than six.
+// The reference's checks come out the same: its ShortInput cases are all "a token ends behind the
+// input", and since the tokens follow each other that is the case exactly when the last token does; its one
+// BadData case (a repeat with nothing in front of it) can only be the very first token.
 template <class LS>
 __device__ __noinline__ HeaderResult read_code_lengths_wave(LS &L, uint32_t b, int64_t win_bit0, uint64_t end_bit)
 {
-    constexpr uint32_t kSpan = 4;   // registers of 64 positions per refill
+    constexpr uint32_t kSeg = 32;      // bits per lane
+    constexpr uint32_t kNone = 0xFF;   // "no length yet" in the scan of last values
+    constexpr uint32_t kLastWord = LS::kWinWords + 1;   // (the window has four zero words behind its data)
     const uint32_t lane = threadIdx.x & 63;
-    // (told to the compiler as uniform, so that the walk stays in scalar registers)
+    // (told to the compiler as uniform)
     const uint32_t total = __builtin_amdgcn_readfirstlane(L.hdr.num_litlen + L.hdr.num_offset);
     b = __builtin_amdgcn_readfirstlane(b);
     // window bit position of the end of the input, as far as 32 bits hold it
     const uint64_t left = end_bit - (uint64_t)win_bit0;   // (the window never starts behind the end)
     const uint32_t end_b = __builtin_amdgcn_readfirstlane(left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left);
-    uint32_t i = 0, last_val = 0;
-    while (i < total) {
-        // packed: codeword bits | extra bits << 4 | symbol << 8 | value of the extra bits << 16
-        uint32_t packed[kSpan];
-#pragma unroll
-        for (uint32_t k = 0; k < kSpan; k++) {
-            const uint32_t bits = fetch_bits(L.win, b + k * 64 + lane);
-            const uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
-            const uint32_t nb = e & 0xFF, sym = e >> 16;
-            const uint32_t xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
-            packed[k] = nb | xb << 4 | sym << 8 | ((bits >> nb) & ((1u << xb) - 1)) << 16;
-        }
-        uint32_t q = 0;   // the next token starts q bits behind b (uniform)
-        while (q < kSpan * 64 && i < total) {
-            uint32_t t = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < kSpan; k++)
-                if (q >> 6 == k) t = (uint32_t)__builtin_amdgcn_readlane((int)packed[k], (int)(q & 63));
-            const uint32_t nb = t & 15, xb = (t >> 4) & 15, sym = (t >> 8) & 0xFF, xv = t >> 16;
-            if (b + q + nb > end_b) return HeaderResult{RSX_SHORT_INPUT, b + q};
-            q += nb;
-            if (sym < 16) {
-                if (lane == 0) L.hdr.lens[i] = (uint8_t)sym;
-                last_val = sym;
-                i++;
-                continue;
-            }
-            uint32_t rep, val;
-            if (sym == 16) {
-                if (i == 0) return HeaderResult{RSX_BAD_DATA, b + q};
-                val = last_val;
-                rep = 3;
-            } else {
-                val = 0;
-                rep = sym == 17 ? 3 : 11;
-            }
-            if (b + q + xb > end_b) return HeaderResult{RSX_SHORT_INPUT, b + q};
-            rep += xv;
-            q += xb;
-            // a run passing the end is clamped (src/decompress/mod.rs:462-467)
-            if (rep > total - i) rep = total - i;
-            for (uint32_t k = lane; k < rep; k += 64) L.hdr.lens[i + k] = (uint8_t)val;
-            last_val = val;
-            i += rep;
-        }
-        b += q;
+    {
+        RSX_LDS uint32_t *lw = (RSX_LDS uint32_t *)L.hdr.lens;   // 320 lengths
+        lw[lane] = 0;
+        if (lane < 16) lw[64 + lane] = 0;
     }
-    WAVE_SYNC();
-    return HeaderResult{RSX_SUCCESS, b};
+    // one token: its bits at `pos`, counted from the lane's segment start, out of the lane's 64-bit piece
+    struct Tok { uint32_t sym, adv, rep; };
+    auto token = [&](uint64_t piece, uint32_t off) {
+        const uint32_t bits = (uint32_t)(piece >> off);
+        const uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
+        const uint32_t nb = e & 0xFF, sym = e >> 16;
+        const uint32_t xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+        const uint32_t xv = (bits >> nb) & ((1u << xb) - 1);
+        return Tok{sym, nb + xb, sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + xv};
+    };
+    uint32_t i_base = 0, carry_last = 0;
+    for (bool first_window = true;; first_window = false) {
+        // the lane's 64 bits from its segment start on: every token that starts in the segment, or up to 13
+        // bits behind it, lies inside with its 14 bits
+        const uint32_t seg0 = b + lane * kSeg;
+        uint64_t piece;
+        {
+            const uint32_t w = seg0 >> 5;
+            const uint32_t w0 = L.win[w < kLastWord ? w : kLastWord], w1 = L.win[w + 1 < kLastWord ? w + 1 : kLastWord],
+                           w2 = L.win[w + 2 < kLastWord ? w + 2 : kLastWord];
+            const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, seg0 & 31), hi = __builtin_amdgcn_alignbit(w2, w1, seg0 & 31);
+            piece = lo | (uint64_t)hi << 32;
+        }
+        uint32_t start = 0, exit_off = 0, reps = 0, lastv = kNone;   // offsets from seg0
+        bool need = true;
+        for (uint32_t pass = 0; pass < 64; pass++) {
+            if (need) {
+                uint32_t off = start;
+                reps = 0;
+                lastv = kNone;
+                while (off < kSeg) {
+                    const Tok t = token(piece, off);
+                    reps += t.rep;
+                    lastv = t.sym < 16 ? t.sym : t.sym == 16 ? lastv : 0u;
+                    off += t.adv;
+                }
+                exit_off = off;
+            }
+            // lane k + 1 starts where lane k stopped
+            const uint32_t handed = (uint32_t)__shfl_up((int)exit_off, 1) - kSeg;
+            need = lane > 0 && handed != start;
+            if (need) start = handed;
+            if (!__any(need)) break;
+        }
+        // where the lane's first length goes, and the length in front of it
+        uint32_t incl = reps, lastscan = lastv;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, o), z = (uint32_t)__shfl_up((int)lastscan, o);
+            if (lane >= o) {
+                incl += y;
+                lastscan = lastscan == kNone ? z : lastscan;
+            }
+        }
+        uint32_t i = i_base + incl - reps;
+        uint32_t cur = (uint32_t)__shfl_up((int)lastscan, 1);
+        if (lane == 0 || cur == kNone) cur = carry_last;
+        if (first_window) {
+            // (the reference looks at the first token's codeword, then at what it repeats)
+            const Tok t0 = token(piece, 0);
+            const uint32_t sym0 = __builtin_amdgcn_readfirstlane(t0.sym), adv0 = __builtin_amdgcn_readfirstlane(t0.adv);
+            if (sym0 == 16) {
+                const uint32_t nb0 = adv0 - 2;
+                return HeaderResult{b + nb0 > end_b ? RSX_SHORT_INPUT : RSX_BAD_DATA, b};
+            }
+        }
+        // the write pass; the lane in which the last length falls reports where the header ends
+        uint32_t end_off = ~0u;
+        if (i < total) {
+            uint32_t off = start;
+            while (off < kSeg && i < total) {
+                const Tok t = token(piece, off);
+                uint32_t rep = t.rep < total - i ? t.rep : total - i;   // a run passing the end is clamped (src/decompress/mod.rs:462-467)
+                if (t.sym < 16) {
+                    if (t.sym) L.hdr.lens[i] = (uint8_t)t.sym;
+                    cur = t.sym;
+                } else if (t.sym == 16) {
+                    if (cur)
+                        for (uint32_t k = 0; k < rep; k++) L.hdr.lens[i + k] = (uint8_t)cur;
+                } else {
+                    cur = 0;
+                }
+                i += rep;
+                off += t.adv;
+            }
+            if (i >= total) end_off = off;
+        }
+        const unsigned long long done = __ballot(end_off != ~0u);
+        if (done) {   // (uniform)
+            const uint32_t k = (uint32_t)__ffsll((long long)done) - 1;
+            const uint32_t end_pos = b + k * kSeg + (uint32_t)__builtin_amdgcn_readlane((int)end_off, (int)k);
+            WAVE_SYNC();
+            return HeaderResult{end_pos > end_b ? RSX_SHORT_INPUT : RSX_SUCCESS, end_pos};
+        }
+        // the header goes on behind this window
+        i_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + i_base;
+        const uint32_t last63 = (uint32_t)__builtin_amdgcn_readlane((int)lastscan, 63);
+        carry_last = last63 == kNone ? carry_last : last63;
+        b += 63 * kSeg + (uint32_t)__builtin_amdgcn_readlane((int)exit_off, 63);
+    }
 }
 
 // src/decompress/mod.rs:355-401: the code lengths of the static code (by the wave)
@@ -689,7 +798,7 @@ __device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_
         }
         if (threadIdx.x == 0) L.hdr.after = r.b;
     }
-    if (RSX_SPLIT_TIMERS && threadIdx.x == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(13, t - th0); th0 = t; }
+    if (RSX_SPLIT_TIMERS && threadIdx.x == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(13, t - th0); th0 = t; SPLIT_T_ADD(20, 1); }
     const uint32_t num_litlen = L.hdr.num_litlen, num_offset = L.hdr.num_offset;
     // the litlen table first: the offset entries carry the index width of its root
     bool ok = build_decode_table_wave(L.tab + kTabLitlen, kTabLitlen, L.hdr.lens, num_litlen, KIND_LITLEN,
@@ -2609,8 +2718,8 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         RSX_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_split_t), z, sizeof z));
         const double d = (double)n;
         fprintf(stderr, "[rsx split] per stream: decode rounds %.1f passes %.1f cycles: stage %.0f header %.0f warm %.0f scan %.0f "
-                        "passes %.0f tail %.0f (header: read %.0f, tables %.0f) | expand groups %.1f cycles: records %.0f walk %.0f copy %.0f flush %.0f\n",
-                t[6] / d, t[7] / d, t[0] / d, t[1] / d, t[2] / d, t[3] / d, t[4] / d, t[5] / d, t[13] / d, t[14] / d, t[12] / d, t[8] / d, t[9] / d,
+                        "passes %.0f tail %.0f (%.1f headers: read %.0f, tables %.0f) | expand groups %.1f cycles: records %.0f walk %.0f copy %.0f flush %.0f\n",
+                t[6] / d, t[7] / d, t[0] / d, t[1] / d, t[2] / d, t[3] / d, t[4] / d, t[5] / d, t[20] / d, t[13] / d, t[14] / d, t[12] / d, t[8] / d, t[9] / d,
                 t[10] / d, t[11] / d);
         fprintf(stderr, "[rsx split] copy per stream: steps %.1f rounds %.1f cycles: scatter %.0f rounds %.0f gather %.0f\n",
                 t[19] / d, t[18] / d, t[15] / d, t[16] / d, t[17] / d);
