@@ -2381,25 +2381,26 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ count)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    // every thread takes a run of consecutive tiles: one scan over the threads' sums, whatever the tile count
+    const uint32_t per = (ntiles + 1023) / 1024;
+    const uint32_t lo = min(threadIdx.x * per, ntiles), hi = min(lo + per, ntiles);
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += tile_flag[i];
+    uint32_t x = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if ((int)(threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
     WG_SYNC();
-    for (uint32_t base = 0; base < ntiles; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t c = i < ntiles ? tile_flag[i] : 0u;
-        uint32_t x = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if ((int)(threadIdx.x & 63) >= o) x += y;
-        }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-        WG_SYNC();
-        uint32_t before = carry;
-        for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) before += wsum[k];
-        if (i < ntiles) tile_pre[i] = before + x - c;
-        WG_SYNC();
-        if (threadIdx.x == 1023) carry = before + x;
-        WG_SYNC();
+    uint32_t before = x - mine, carry = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        if (k < (threadIdx.x >> 6)) before += wsum[k];
+        carry += wsum[k];
+    }
+    for (uint32_t i = lo; i < hi; i++) {
+        tile_pre[i] = before;
+        before += tile_flag[i];
     }
     if (threadIdx.x == 0) {
         tile_pre[ntiles] = carry;
