@@ -80,10 +80,18 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def make_streams(distinct, buf_bytes, fmt, level, seed0):
+def make_streams(distinct, buf_bytes, fmt, level, seed0, compressor="reference"):
     import corpus
     import oracle_lib as orc
     texts = [corpus.text(buf_bytes, seed0 + i) for i in range(distinct)]
+    if compressor == "zlib":   # one stream without joints, a block every 16K symbols
+        import zlib
+        wbits = {0: -15, 1: 15, 2: 31}[fmt]
+        streams = []
+        for t in texts:
+            co = zlib.compressobj(level, zlib.DEFLATED, wbits)
+            streams.append(np.frombuffer(co.compress(t) + co.flush(), dtype=np.uint8))
+        return texts, streams
     flat = np.frombuffer(b"".join(texts), dtype=np.uint8)
     in_off = np.arange(distinct + 1, dtype=np.uint64) * np.uint64(buf_bytes)
     out, out_off, sizes, status = orc.batch_compress(flat, in_off, fmt, level, threads=host_threads())
@@ -230,7 +238,7 @@ def bench_decompress(args, ctx):
     buf = args.buf_kib * 1024
     n = args.streams
     distinct = min(args.distinct, n)
-    texts, streams = make_streams(distinct, buf, fmt, level, seed0=1000 * ctx.rank)
+    texts, streams = make_streams(distinct, buf, fmt, level, seed0=1000 * ctx.rank, compressor=args.compressor)
     idx = [i % distinct for i in range(n)]   # stream i is a private copy of distinct stream i % distinct
     d_in, d_in_off, in_off = device_batch(ctx, streams, idx)
     total_in, total_out = int(in_off[-1]), n * buf
@@ -257,7 +265,8 @@ def bench_decompress(args, ctx):
             "workload": "batch gzip decompress, %d x %d KiB level-6 enwik-style text per GPU" % (n, args.buf_kib),
             "op": "decompress", "format": "gzip", "level": level, "streams_per_gpu": n,
             "buf_bytes": buf, "distinct_buffers": distinct, "compressed_ratio": total_out / total_in,
-            "compressor": "CPU restatement of the reference, 256 KiB sync-flushed segments",
+            "compressor": ("CPU restatement of the reference, 256 KiB sync-flushed segments"
+                           if args.compressor == "reference" else "zlib, one stream without joints"),
             "parallelism": "batch sharded over %d GPU(s), no data-path collective" % ctx.world,
             "verified": ok, "verified_rows": n,
         },
@@ -519,6 +528,8 @@ def main():
                     help="decompress = gzip level-6 text (headline) with the compress leg attached; "
                          "compress = zlib level-6 mixed alone; large = one --large-mib MiB buffer, batch of 1")
     ap.add_argument("--large-mib", type=int, default=64, help="--op large: size of the single buffer")
+    ap.add_argument("--compressor", choices=["reference", "zlib"], default="reference",
+                    help="decompress only: who made the streams (reference = the headline's)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     argv = sys.argv[1:]
     args = ap.parse_args(argv)
