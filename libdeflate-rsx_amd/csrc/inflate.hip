@@ -45,6 +45,9 @@
 #ifndef RSX_DBG
 #define RSX_DBG 0   // development checks
 #endif
+#ifndef RSX_TABLE_CHECK
+#define RSX_TABLE_CHECK 0   // 1: the table build fails when it has left an entry unwritten (development)
+#endif
 #ifndef RSX_TWO_BARRIERS
 #define RSX_TWO_BARRIERS 0   // 1: the copy phase's rounds separate their reads from their writes (for comparison)
 #endif
@@ -188,8 +191,12 @@ __device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t len, uint
     return (off_base(sym) << 16) | (kTokMatch << 9) | back | (len << 5) | (len + off_extra(sym));
 }
 
-// the precode's entries: symbol << 16 | codeword length
-__device__ inline uint32_t make_precode_entry(uint32_t sym, uint32_t len) { return (sym << 16) | len; }
+// the precode's entries: symbol << 16 | (codeword length + extra bits of the symbol) << 8 | codeword length
+__device__ inline uint32_t make_precode_entry(uint32_t sym, uint32_t len)
+{
+    const uint32_t xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+    return (sym << 16) | ((len + xb) << 8) | len;
+}
 
 // Everything a workgroup keeps in LDS.  Three groups of arrays are never live at
 // the same time and share storage: header parsing scratch, the per-sub-sequence
@@ -199,7 +206,6 @@ struct HeaderScratch {
     uint16_t sorted_syms[288];
     uint8_t lens[288 + 32 + 140];
     uint32_t num_litlen, num_offset;   // alphabet sizes of the block whose tables are being built
-    uint32_t len_counts[16], offsets[16];   // working arrays of the table build
     uint32_t plan;                     // 0 nothing to build, 1 the static code, 3 a dynamic header whose counts start at `after`
     uint32_t after;                    // window bit position behind the header
 };
@@ -264,78 +270,88 @@ typedef RSX_LDS StreamLds LdsStream;
 #define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // The litlen or offset table (src/decompress/mod.rs:1324-1495: same checks, same root and
-// subtable layout, the entries in this file's format) built by the 64 lanes of one wave.
-// Everything that decides the layout -- code-space checks, the canonical first codeword of
-// each length, the sizes and places of the subtables -- is uniform in the wave and kept in scalar
-// registers: the counts of the sixteen lengths and the running starts of their symbols sit in lanes 0..15
-// of two vector registers and are read and written by lane number, so the serial parts of the build wait
-// for no LDS round trip.  The lanes share the counting, the sorting of the symbols and the filling: the
-// codewords of one length fill all their root entries at once (lanes split into symbol x replica), a
-// subtable entry is replicated by the lanes.  `table_index` is where table[0] sits
-// in the decoder's table space (subtable pointers are absolute byte offsets); `root_bits` the index width of
-// the litlen root, for the entries that lead back to it (ignored when table_bits_ret is given:
-// then this IS the litlen table and its own shrunk width is used and returned).
+// subtable layout, the entries in this file's format) built by the 64 lanes of one wave.  The wave is
+// one of many on its CU and gets an instruction issued every twenty-odd cycles, so the build is shaped to
+// need few wave instructions, not little work per lane:
+// * symbols stay in symbol order, 64 to a batch.  Four ballots over the bits of the lengths give every
+//   lane the set of lanes with its length (its rank among them is the canonical order) and lanes 0..15 the
+//   count of "their" length; the counts of the sixteen lengths, the first codeword of each and the index
+//   of its first symbol live in lanes 0..15 of three registers, read by lane number;
+// * a codeword no longer than the root index writes its own root entries (the canonical codeword,
+//   bit-reversed, is the low end of the index; every value of the bits above it is a replica); the few
+//   codewords with more than eight replicas are written by all lanes together;
+// * longer codewords are put in canonical order (LDS) and taken 64 at a time: which lengths occur under a
+//   codeword's root prefix follows from the first codewords and counts alone, so every lane knows its
+//   subtable's size without looking at its neighbours, and a prefix sum over "first codeword of its
+//   subtable" lanes gives the subtables' places -- the order and the sizes the serial build arrives at.
+// `table_index` is where table[0] sits in the decoder's table space (subtable pointers are absolute byte
+// offsets); `root_bits` the index width of the litlen root, for the entries that lead back to it (ignored
+// when table_bits_ret is given: then this IS the litlen table and its own shrunk width is used and returned).
 __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, uint32_t table_index,
                                                      const RSX_LDS uint8_t *lens, uint32_t num_syms, int kind,
-                                                     uint32_t table_bits, uint32_t max_codeword_len,
-                                                     uint32_t root_bits, RSX_LDS uint16_t *sorted_syms,
-                                                     RSX_LDS uint32_t *table_bits_ret,
-                                                     RSX_LDS uint32_t *len_counts, RSX_LDS uint32_t *offsets)
+                                                     uint32_t table_bits, uint32_t root_bits,
+                                                     RSX_LDS uint16_t *sorted_syms, RSX_LDS uint32_t *table_bits_ret)
 {
+    constexpr uint32_t kBatches = 5;   // 288 symbols at most
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1;
     num_syms = __builtin_amdgcn_readfirstlane(num_syms);
     table_bits = __builtin_amdgcn_readfirstlane(table_bits);
-    max_codeword_len = __builtin_amdgcn_readfirstlane(max_codeword_len);   // (at most 15)
     root_bits = __builtin_amdgcn_readfirstlane(root_bits);
-    if (lane < 16) len_counts[lane] = 0;
+#if RSX_TABLE_CHECK
+    for (uint32_t i = lane; i < (kind == KIND_LITLEN ? (uint32_t)kLitlenEnough : (uint32_t)kOffsetEnough); i += 64) table[i] = 0;
     WAVE_SYNC();
-    for (uint32_t s = lane; s < num_syms; s += 64)
-        __hip_atomic_fetch_add(&len_counts[lens[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    WAVE_SYNC();
-    // lane l < 16 holds the count of length l
-    const uint32_t cntv = lane < 16 ? len_counts[lane] : 0u;
+#endif
+    uint32_t len_k[kBatches], rank_k[kBatches];   // of symbol 64 k + lane: its length, its rank among the symbols of that length
+    uint32_t cntv = 0;      // lane l < 16: symbols of length l
+    uint32_t one_sym = 0;   // a symbol of length 1
+#pragma unroll
+    for (uint32_t k = 0; k < kBatches; k++) {
+        len_k[k] = 0;
+        rank_k[k] = 0;
+        if (k * 64 < num_syms) {   // (uniform)
+            const uint32_t s = k * 64 + lane;
+            const bool valid = s < num_syms;
+            const uint32_t mylen = valid ? (uint32_t)lens[s] & 15u : 0u;
+            const unsigned long long all = __ballot(valid);
+            unsigned long long own = all, idx = all;   // lanes with this lane's length / with length (lane & 15)
+#pragma unroll
+            for (uint32_t bit = 0; bit < 4; bit++) {
+                const unsigned long long has = __ballot((mylen >> bit & 1) != 0);
+                own &= (mylen >> bit & 1) ? has : ~has;
+                idx &= (lane >> bit & 1) ? has : ~has;
+            }
+            rank_k[k] = (uint32_t)__shfl((int)cntv, (int)mylen) + (uint32_t)__popcll(own & below);
+            len_k[k] = mylen;
+            cntv += (uint32_t)__popcll(idx);
+            const unsigned long long ones = __ballot(mylen == 1);
+            if (ones) one_sym = k * 64 + (uint32_t)__ffsll((long long)ones) - 1;
+        }
+    }
     auto cnt = [&](uint32_t len) { return (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)len); };
-    while (max_codeword_len > 1 && cnt(max_codeword_len) == 0) max_codeword_len--;
+    uint32_t max_codeword_len = 1;
+    {
+        const unsigned long long used = __ballot(lane >= 1 && lane < 16 && cntv != 0);
+        if (used) max_codeword_len = 63u - (uint32_t)__clzll((long long)used);
+    }
     if (table_bits_ret) {
         if (table_bits > max_codeword_len) table_bits = max_codeword_len;
         if (lane == 0) *table_bits_ret = table_bits;
         root_bits = table_bits;
     }
-    // lane l < 16 of startv: where the symbols of length l start in sorted_syms; of runv: the same, advanced
-    // by the sort
-    uint32_t startv = 0, codespace_used = 0;
+    // lane l of fcv: the canonical (MSB-first) first codeword of length l; of startv: how many codewords are shorter
+    uint32_t fcv = 0, startv = 0, codespace_used = 0, num_coded = 0;
     {
-        uint32_t at = 0;
-        for (uint32_t len = 0; len <= max_codeword_len; len++) {
-            startv = lane == len ? at : startv;
+        uint32_t fc = 0;
+        for (uint32_t len = 1; len <= max_codeword_len; len++) {
+            fcv = lane == len ? fc : fcv;
+            startv = lane == len ? num_coded : startv;
             const uint32_t c = cnt(len);
-            at += c;
-            if (len >= 1) codespace_used = (codespace_used << 1) + c;
+            num_coded += c;
+            codespace_used = (codespace_used << 1) + c;
+            fc = (fc + c) << 1;
         }
     }
-    auto start = [&](uint32_t len) { return (uint32_t)__builtin_amdgcn_readlane((int)startv, (int)len); };
-    // stable counting sort, 64 symbols at a time: a lane's place is the running start of its
-    // length plus the number of lower lanes with the same length
-    {
-        uint32_t runv = startv;
-        for (uint32_t base = 0; base < num_syms; base += 64) {
-            const uint32_t s = base + lane;
-            const uint32_t mylen = s < num_syms ? lens[s] : 0xFFu;
-            for (uint32_t len = 0; len <= max_codeword_len; len++) {
-                const unsigned long long same = __ballot(mylen == len);
-                if (same) {   // (uniform)
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)runv, (int)len);
-                    if (mylen == len) sorted_syms[o + (uint32_t)__popcll(same & below)] = (uint16_t)s;
-                    runv = lane == len ? o + (uint32_t)__popcll(same) : runv;
-                }
-            }
-        }
-    }
-    WAVE_SYNC();
-    const uint32_t first_sym = cnt(0);     // index into sorted_syms of the first symbol with a codeword
-    const uint32_t end_sym = num_syms;     // and behind the last one
-
     if (codespace_used > (1u << max_codeword_len)) return false;
     if (codespace_used < (1u << max_codeword_len)) {
         uint32_t s;
@@ -343,7 +359,7 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, ui
             s = 0;
         } else {
             if (codespace_used != (1u << (max_codeword_len - 1)) || cnt(1) != 1) return false;
-            s = sorted_syms[first_sym];
+            s = one_sym;
         }
         const uint32_t e = make_entry(kind, s, 1, root_bits);
         for (uint32_t i = lane; i < (1u << table_bits); i += 64) table[i] = e;
@@ -351,81 +367,94 @@ __device__ __noinline__ bool build_decode_table_wave(RSX_LDS uint32_t *table, ui
         return true;
     }
 
-    // root table: the codewords of one length fill all their entries at once (canonical codeword number,
-    // bit-reversed, is the low end of the table index; every value of the bits above it is a replica).
-    // The lanes are split into (symbol, replica): a power of two of symbols side by side.
-    uint32_t first_code = 0;             // canonical (MSB-first) first codeword of `len`
-    uint32_t len = 1;
-    for (; len <= table_bits; len++) {
-        const uint32_t count = cnt(len);
-        if (count) {   // (uniform)
-            const uint32_t sh = count >= 64 ? 6u : 32u - (uint32_t)__clz((int)(count - 1));   // log2 of the symbols side by side (count 1: 0)
-            const uint32_t reps = 1u << (table_bits - len);
-            const uint32_t sp = start(len);
-            for (uint32_t j = lane & ((1u << sh) - 1); j < count; j += 1u << sh) {
-                const uint32_t rev = __brev(first_code + j) >> (32 - len);
-                const uint32_t e = make_entry(kind, sorted_syms[sp + j], len, root_bits);
-                for (uint32_t rep = lane >> sh; rep < reps; rep += 64u >> sh) table[rev | rep << len] = e;
-            }
+    // codewords that fit the root index
+    const uint32_t root_coded = max_codeword_len > table_bits
+                                    ? (uint32_t)__builtin_amdgcn_readlane((int)startv, (int)(table_bits + 1)) : num_coded;
+#pragma unroll
+    for (uint32_t k = 0; k < kBatches; k++) {
+        if (k * 64 >= num_syms) continue;   // (uniform)
+        const uint32_t len = len_k[k], sym = k * 64 + lane;
+        const uint32_t code = (uint32_t)__shfl((int)fcv, (int)len) + rank_k[k];
+        const uint32_t rev = len ? __brev(code) >> (32 - len) : 0u;
+        const bool in_root = len != 0 && len <= table_bits;
+        const uint32_t e = make_entry(kind, sym, in_root ? len : 1u, root_bits);
+        if (in_root && len + 3 >= table_bits) {
+            for (uint32_t rep = 0; rep < (1u << (table_bits - len)); rep++) table[rev | rep << len] = e;
         }
-        first_code = (first_code + count) << 1;
+        // the few short codewords have many replicas: all lanes write those of one
+        unsigned long long wide = __ballot(in_root && len + 3 < table_bits);
+        while (wide) {   // (uniform)
+            const uint32_t j = (uint32_t)__ffsll((long long)wide) - 1;
+            wide &= wide - 1;
+            const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)j);
+            const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)j);
+            const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rev, (int)j);
+            for (uint32_t rep = lane; rep < (1u << (table_bits - lj)); rep += 64) table[rj | rep << lj] = ej;
+        }
+        // longer codewords wait in canonical order (the lane exchange stands outside the branch: a lane that is
+        // switched off hands nothing on)
+        const uint32_t first_of_len = (uint32_t)__shfl((int)startv, (int)len);
+        if (len > table_bits) sorted_syms[first_of_len - root_coded + rank_k[k]] = (uint16_t)(sym | len << 9);
     }
+    WAVE_SYNC();
     if (max_codeword_len <= table_bits) {   // no codeword is longer than the root index
-        WAVE_SYNC();
+#if RSX_TABLE_CHECK
+        bool hole = false;
+        for (uint32_t i = lane; i < (1u << table_bits); i += 64) hole = hole || (table[i] & 31) == 0;
+        if (__any(hole)) return false;
+#endif
         return true;
     }
 
-    // subtables (codewords longer than table_bits), in canonical order as the serial build;
-    // `len` is the first length behind the root, first_code its first codeword
-    while (cnt(len) == 0) {
-        len++;
-        first_code <<= 1;
-    }
-    uint32_t codeword = __brev(first_code) >> (32 - len);
-    uint32_t cur_table_end = 1u << table_bits;
-    uint32_t subtable_prefix = ~0u;
-    uint32_t subtable_start = 0;
-    uint32_t sp = start(len);
-    bool last = false;
-    for (; len <= max_codeword_len && !last; len++) {
-        const uint32_t count = cnt(len);
-        for (uint32_t j0 = 0; j0 < count && !last; j0 += 64) {
-            // the symbols of up to 64 codewords in one read; the walk takes them by lane number
-            const uint32_t symv = sp + j0 + lane < end_sym ? (uint32_t)sorted_syms[sp + j0 + lane] : 0u;
-            const uint32_t j1 = count - j0 < 64 ? count - j0 : 64;
-            for (uint32_t j = 0; j < j1; j++) {
-                if ((codeword & ((1u << table_bits) - 1)) != subtable_prefix) {
-                    subtable_prefix = codeword & ((1u << table_bits) - 1);
-                    subtable_start = cur_table_end;
-                    uint32_t subtable_bits = len - table_bits;
-                    uint32_t sub_used = count - j0 - j;   // codewords of this length that are left
-                    while (sub_used < (1u << subtable_bits)) {
-                        subtable_bits++;
-                        sub_used = (sub_used << 1) + (table_bits + subtable_bits <= 15 ? cnt(table_bits + subtable_bits) : 0);
-                    }
-                    cur_table_end = subtable_start + (1u << subtable_bits);
-                    if (lane == 0)
-                        table[subtable_prefix] = kEntPointer | (4 * (table_index + subtable_start) << 16) |
-                                                 (subtable_bits << 12) | (table_bits << 5) | table_bits;
-                }
-                const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)symv, (int)j);
-                const uint32_t e = make_entry(kind, sym, len - table_bits, root_bits);
-                const uint32_t stride = 1u << (len - table_bits);
-                for (uint32_t i = subtable_start + (codeword >> table_bits) + lane * stride; i < cur_table_end;
-                     i += 64 * stride)
-                    table[i] = e;
-                if (codeword == (1u << len) - 1) {   // the last codeword of a complete code
-                    last = true;
-                    break;
-                }
-                const uint32_t bit = 1u << (31 - __clz(codeword ^ ((1u << len) - 1)));
-                codeword &= bit - 1;
-                codeword |= bit;
+    const uint32_t num_long = num_coded - root_coded;
+    uint32_t slots_before = 0;   // entries of the subtables in front of this batch's
+    for (uint32_t j0 = 0; j0 < num_long; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool valid = j < num_long;
+        const uint32_t packed = valid ? (uint32_t)sorted_syms[j] : (uint32_t)((table_bits + 1) << 9);
+        const uint32_t sym = packed & 511, len = packed >> 9;
+        const uint32_t code = (uint32_t)__shfl((int)fcv, (int)len) + (j + root_coded - (uint32_t)__shfl((int)startv, (int)len));
+        const uint32_t prefix = code >> (len - table_bits);   // the codeword's first table_bits bits
+        // the shortest and the longest codeword under this prefix, and the first of the shortest ones
+        uint32_t minl = 0, maxl = 0, first_code = 0;
+        for (uint32_t l = table_bits + 1; l <= max_codeword_len; l++) {   // (uniform)
+            const uint32_t fc = (uint32_t)__builtin_amdgcn_readlane((int)fcv, (int)l), c = cnt(l);
+            if (c == 0) continue;
+            const uint32_t lo = max(fc, prefix << (l - table_bits)), hi = min(fc + c, (prefix + 1) << (l - table_bits));
+            if (lo < hi) {
+                first_code = minl ? first_code : lo;
+                minl = minl ? minl : l;
+                maxl = l;
             }
         }
-        sp += count;
+        const uint32_t sub_bits = maxl - table_bits;   // (a valid lane's own codeword lies under its prefix: maxl >= len)
+        const bool head = valid && len == minl && code == first_code;
+        uint32_t incl = head ? 1u << sub_bits : 0u;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += y;
+        }
+        incl += slots_before;
+        slots_before = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (valid) {
+            const uint32_t start = (1u << table_bits) + incl - (1u << sub_bits);
+            const uint32_t rev = __brev(code) >> (32 - len);
+            const uint32_t e = make_entry(kind, sym, len - table_bits, root_bits);
+            const uint32_t stride = 1u << (len - table_bits);
+            for (uint32_t i = start + (rev >> table_bits); i < start + (1u << sub_bits); i += stride) table[i] = e;
+            if (head)
+                table[rev & ((1u << table_bits) - 1)] = kEntPointer | (4 * (table_index + start) << 16) |
+                                                        (sub_bits << 12) | (table_bits << 5) | table_bits;
+        }
     }
     WAVE_SYNC();
+#if RSX_TABLE_CHECK
+    {   // development: an entry that nothing wrote would stall the decoder
+        bool hole = false;
+        for (uint32_t i = lane; i < (1u << table_bits) + slots_before; i += 64) hole = hole || (table[i] & 31) == 0;
+        if (__any(hole)) return false;
+    }
+#endif
     return true;
 }
 
@@ -563,7 +592,7 @@ __device__ __noinline__ HeaderResult read_dynamic_preamble_wave(LS &L, uint32_t 
             if (mylen == len) mycode = first_code[len] + rank;
         const uint32_t rev = mylen ? __brev(mycode) >> (32 - mylen) : 0u;
         const uint32_t word = mylen | rev << 8;
-        e0 = e1 = 0;
+        e0 = e1 = make_precode_entry(0, 1);   // (a complete code leaves none of them: every index ends one codeword)
         for (uint32_t sym = 0; sym < 19; sym++) {
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)sym);
             const uint32_t len = w & 0xFF, mask = (1u << len) - 1;
@@ -617,10 +646,13 @@ __device__ __noinline__ HeaderResult read_code_lengths_wave(LS &L, uint32_t b, i
     auto token = [&](uint64_t piece, uint32_t off) {
         const uint32_t bits = (uint32_t)(piece >> off);
         const uint32_t e = L.hdr.precode[bits & ((1u << kPrecodeBits) - 1)];
-        const uint32_t nb = e & 0xFF, sym = e >> 16;
-        const uint32_t xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
-        const uint32_t xv = (bits >> nb) & ((1u << xb) - 1);
-        return Tok{sym, nb + xb, sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + xv};
+        const uint32_t nb = e & 0xFF, adv = (e >> 8) & 0xFF, sym = e >> 16;
+        const uint32_t xv = (bits >> nb) & ((1u << (adv - nb)) - 1);
+        return Tok{sym, adv, sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + xv};
+    };
+    // (only how far the token at `off` reaches)
+    auto token_adv = [&](uint64_t piece, uint32_t off) {
+        return (L.hdr.precode[(uint32_t)(piece >> off) & ((1u << kPrecodeBits) - 1)] >> 8) & 0xFF;
     };
     uint32_t i_base = 0, carry_last = 0;
     for (bool first_window = true;; first_window = false) {
@@ -635,19 +667,12 @@ __device__ __noinline__ HeaderResult read_code_lengths_wave(LS &L, uint32_t b, i
             const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, seg0 & 31), hi = __builtin_amdgcn_alignbit(w2, w1, seg0 & 31);
             piece = lo | (uint64_t)hi << 32;
         }
-        uint32_t start = 0, exit_off = 0, reps = 0, lastv = kNone;   // offsets from seg0
+        uint32_t start = 0, exit_off = 0;   // offsets from seg0
         bool need = true;
         for (uint32_t pass = 0; pass < 64; pass++) {
             if (need) {
                 uint32_t off = start;
-                reps = 0;
-                lastv = kNone;
-                while (off < kSeg) {
-                    const Tok t = token(piece, off);
-                    reps += t.rep;
-                    lastv = t.sym < 16 ? t.sym : t.sym == 16 ? lastv : 0u;
-                    off += t.adv;
-                }
+                while (off < kSeg) off += token_adv(piece, off);
                 exit_off = off;
             }
             // lane k + 1 starts where lane k stopped
@@ -655,6 +680,14 @@ __device__ __noinline__ HeaderResult read_code_lengths_wave(LS &L, uint32_t b, i
             need = lane > 0 && handed != start;
             if (need) start = handed;
             if (!__any(need)) break;
+        }
+        // the lane's tokens: how many lengths they stand for, and the last length they set
+        uint32_t reps = 0, lastv = kNone;
+        for (uint32_t off = start; off < kSeg;) {
+            const Tok t = token(piece, off);
+            reps += t.rep;
+            lastv = t.sym < 16 ? t.sym : t.sym == 16 ? lastv : 0u;
+            off += t.adv;
         }
         // where the lane's first length goes, and the length in front of it
         uint32_t incl = reps, lastscan = lastv;
@@ -802,12 +835,10 @@ __device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_
     const uint32_t num_litlen = L.hdr.num_litlen, num_offset = L.hdr.num_offset;
     // the litlen table first: the offset entries carry the index width of its root
     bool ok = build_decode_table_wave(L.tab + kTabLitlen, kTabLitlen, L.hdr.lens, num_litlen, KIND_LITLEN,
-                                      kLitlenBits, 15, 0, L.hdr.sorted_syms, &L.litlen_tablebits,
-                                      L.hdr.len_counts, L.hdr.offsets);
+                                      kLitlenBits, 0, L.hdr.sorted_syms, &L.litlen_tablebits);
     WAVE_SYNC();
     ok = ok && build_decode_table_wave(L.tab, 0, L.hdr.lens + num_litlen, num_offset, KIND_OFFSET, kOffsetBits,
-                                       15, L.litlen_tablebits, L.hdr.sorted_syms, nullptr, L.hdr.len_counts,
-                                       L.hdr.offsets);
+                                       L.litlen_tablebits, L.hdr.sorted_syms, nullptr);
     if (RSX_SPLIT_TIMERS && threadIdx.x == 0) SPLIT_T_ADD(14, SPLIT_T_NOW() - th0);
     if (threadIdx.x == 0) {
         if (!ok) {
