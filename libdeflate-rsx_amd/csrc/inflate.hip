@@ -756,14 +756,16 @@ __device__ inline void load_static_lens(LS &L)
     L.hdr.num_offset = 32;
 }
 
+// (The stream's body and its length come by value: a reference to the stream context would keep the
+// whole context in scratch memory, written by every lane of every workgroup.)
 // First wave's part of a round: when the stream is between blocks, lane 0 reads the next
 // block header from the staged window (src/decompress/mod.rs:225-252), then the wave builds
 // the decode tables.  Leaves L.in_block / L.stored_len / L.status / L.restage set.
 template <class LS>
-__device__ __noinline__ void parse_block_header(LS &L, const StreamCtx &c, int64_t win_bit0)
+__device__ __noinline__ void parse_block_header(LS &L, const uint8_t *body, uint64_t body_len, int64_t win_bit0)
 {
     constexpr uint32_t kWinLimitBits = LS::kWinLimitBits;
-    const uint64_t end_bit = c.body_len * 8;
+    const uint64_t end_bit = body_len * 8;
     uint32_t b = (uint32_t)((int64_t)L.bitpos - win_bit0);
     L.restage = 0;
     L.hdr.plan = 0;
@@ -783,11 +785,11 @@ __device__ __noinline__ void parse_block_header(LS &L, const StreamCtx &c, int64
     if (type == 0) {
         // stored block: byte-align, LEN / NLEN (src/decompress/mod.rs:282-304)
         uint64_t byte = ((uint64_t)(win_bit0 + b) + 7) >> 3;
-        if (byte + 4 > c.body_len) {
+        if (byte + 4 > body_len) {
             L.status = RSX_SHORT_INPUT;
             return;
         }
-        const uint8_t *p = c.body + byte;
+        const uint8_t *p = body + byte;
         uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
         if (len != (~nlen & 0xFFFF)) {
             L.status = RSX_BAD_DATA;
@@ -810,10 +812,10 @@ __device__ __noinline__ void parse_block_header(LS &L, const StreamCtx &c, int64
 }
 
 template <class LS>
-__device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_bit0)
+__device__ __noinline__ void header_step(LS &L, const uint8_t *body, uint64_t body_len, int64_t win_bit0)
 {
     unsigned long long th0 = SPLIT_T_NOW();
-    if (threadIdx.x == 0) parse_block_header(L, c, win_bit0);
+    if (threadIdx.x == 0) parse_block_header(L, body, body_len, win_bit0);
     WAVE_SYNC();
     const uint32_t plan = L.hdr.plan;   // (uniform)
     if (plan == 0) return;
@@ -822,8 +824,8 @@ __device__ __noinline__ void header_step(LS &L, const StreamCtx &c, int64_t win_
         WAVE_SYNC();
     }
     if (plan == 3) {
-        HeaderResult r = read_dynamic_preamble_wave(L, L.hdr.after, win_bit0, c.body_len * 8);
-        if (r.code == RSX_SUCCESS) r = read_code_lengths_wave(L, r.b, win_bit0, c.body_len * 8);
+        HeaderResult r = read_dynamic_preamble_wave(L, L.hdr.after, win_bit0, body_len * 8);
+        if (r.code == RSX_SUCCESS) r = read_code_lengths_wave(L, r.b, win_bit0, body_len * 8);
         WAVE_SYNC();   // (everyone has read hdr.after)
         if (r.code != RSX_SUCCESS) {   // (uniform)
             if (threadIdx.x == 0) L.status = r.code;
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
         if (!L.in_block) {
             STAT_BEGIN();
             WG_SYNC();
-            if (tid < 64) header_step(*(LdsStream *)&L, c, win_bit0);
+            if (tid < 64) header_step(*(LdsStream *)&L, c.body, c.body_len, win_bit0);
             WG_SYNC();
             STAT_END(tH);
         }
@@ -2009,7 +2011,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(0, t - ts); ts = t; }
         if (!L.in_block) {
             WG_SYNC();
-            if (tid < 64) header_step(*(LdsDecode *)&L, c, win_bit0);
+            if (tid < 64) header_step(*(LdsDecode *)&L, c.body, c.body_len, win_bit0);
             WG_SYNC();
             if (RSX_SPLIT_TIMERS && tid == 0) SPLIT_T_ADD(1, SPLIT_T_NOW() - ts);
         }
