@@ -143,12 +143,25 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
         for (int i = tid; i < 2048; i += kThreads) tab[i] = tables[i];
     }
     WG_SYNC();
-    for (uint32_t slot = blockIdx.x * kSegsPerWg; slot < (blockIdx.x + 1) * kSegsPerWg; slot++) {
+    const uint32_t slot_end = (blockIdx.x + 1) * kSegsPerWg;
+    for (uint32_t slot = blockIdx.x * kSegsPerWg, run = 1; slot < slot_end; slot += run) {
     uint32_t item;
+    run = 1;
     SegInfo s = locate(in, starts, lens, n, seg_start, segs_per_item, slot, &item);
     if (!s.valid) continue;  // slot past the end of a short item or of the batch: never read by the fold (uniform)
+    // CRC-32: the workgroup's slots that hold consecutive segments of this item are reduced in one go (one
+    // final multiplication and one reduction over the lanes for all of them); the result goes to the last
+    // of the slots and zeros to the others, which the fold turns into the same value.
+    if (KIND == RSX_CHECKSUM_CRC32) {
+        while (slot + run < slot_end) {
+            uint32_t item2;
+            const SegInfo s2 = locate(in, starts, lens, n, seg_start, segs_per_item, slot + run, &item2);
+            if (!s2.valid || item2 != item || s2.seg != s.seg + run) break;
+            run++;
+        }
+    }
     const uint64_t seg_begin = (uint64_t)s.seg * kSeg;
-    const uint32_t L = (uint32_t)((s.len - seg_begin) < kSeg ? (s.len - seg_begin) : kSeg);
+    const uint32_t L = (uint32_t)((s.len - seg_begin) < (uint64_t)run * kSeg ? (s.len - seg_begin) : (uint64_t)run * kSeg);
     const uint8_t *p = s.base + seg_begin;
     // 16-byte unit grid over the global address space
     const uintptr_t addr = (uintptr_t)p;
@@ -191,7 +204,8 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
             uint32_t from = full_units ? 0 : head;
             const uint8_t *t = grid + 16 * (size_t)full_units;
             for (uint32_t b = from; b < tail; b++) crc = (crc >> 8) ^ tab[(crc ^ t[b]) & 0xFF];
-            partial[slot] = make_uint2(crc, 0);
+            for (uint32_t k = 0; k + 1 < run; k++) partial[slot + k] = make_uint2(0, 0);
+            partial[slot + run - 1] = make_uint2(crc, 0);
         }
     } else {
         // weights: byte at grid offset g has data index i = g - head and weight (L - i)
