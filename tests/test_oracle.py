@@ -129,6 +129,27 @@ def test_result_codes():
     assert o.decompress(zl[:5], len(t), o.FMT_ZLIB)[0] == o.SHORT_INPUT
 
 
+def test_dynamic_headers_built_by_hand():
+    """The oracle on block headers assembled bit by bit (tests/handmade.py): what zlib decodes it decodes
+    to the same bytes; a run across the end of the code lengths is clamped (src/decompress/mod.rs:462-467;
+    zlib rejects it); a repeat with nothing in front of it is BadData, or ShortInput when the input ends inside
+    its codeword (:436-456 checks the bits first); a header cut anywhere is ShortInput."""
+    import handmade
+    streams, caps, text = handmade.header_cases()
+    for k in (0, 1, 2):
+        r, _, out = o.decompress(streams[k], caps[k], 0)
+        assert r == o.SUCCESS and out == zlib.decompress(streams[k], -15)
+    assert o.decompress(streams[0], caps[0], 0)[2] == text
+    r, _, out = o.decompress(streams[3], caps[3], 0)
+    assert r == o.SUCCESS and out == bytes(range(200))
+    with pytest.raises(zlib.error):
+        zlib.decompress(streams[3], -15)
+    assert o.decompress(streams[4], caps[4], 0)[0] == o.BAD_DATA
+    assert o.decompress(streams[5], caps[5], 0)[0] == o.SHORT_INPUT
+    for s_, c_ in zip(streams[6:], caps[6:]):
+        assert o.decompress(s_, c_, 0)[0] == o.SHORT_INPUT
+
+
 def test_headers():
     # src/compress/mod.rs:2257-2269 (zlib level hint, FCHECK) and :2309-2327 (gzip XFL/OS)
     assert o.compress(b"x", 6, o.FMT_ZLIB)[:2] == b"\x78\x9c"
