@@ -34,11 +34,15 @@ constexpr uint32_t kPoly = 0xEDB88320u;
 constexpr uint32_t kAdlerMod = 65521u;
 
 // table offsets (in u32) inside rsx_engine::d_crc_tables
+#ifndef RSX_CRC_GROUP
+#define RSX_CRC_GROUP 4
+#endif
+constexpr uint32_t kGroup = RSX_CRC_GROUP;   // consecutive 16-byte units a lane takes between two multiplications
 constexpr int kTabSlice = 0;     // 4 x 256: slice-by-4 tables
-constexpr int kTabMulC = 1024;   // 4 x 256: multiply a state byte by x^(128*(kThreads-1))
-constexpr int kTabPow = 2048;    // 256: x^(128*j)
-constexpr int kTabXSeg = 2304;   // x^(8*kSeg)
-constexpr int kTabWords = 2305;
+constexpr int kTabMulC = 1024;   // 4 x 256: multiply a state byte by x^(128*kGroup*(kThreads-1))
+constexpr int kTabPow = 2048;    // kGroup * 256: x^(128*j)
+constexpr int kTabXSeg = kTabPow + kGroup * 256;   // x^(8*kSeg)
+constexpr int kTabWords = kTabXSeg + 1;
 
 // ---- GF(2)[x] mod P helpers in the reflected representation (x^0 = 1<<31) ----
 
@@ -172,29 +176,39 @@ __global__ __launch_bounds__(kThreads) void checksum_partial_kernel(
     const uint32_t tail = span & 15;                       // bytes after the last full unit
 
     if (KIND == RSX_CHECKSUM_CRC32) {
+        // lane l takes the groups l, l + kThreads, ... of kGroup consecutive units: one multiplication by
+        // x^(128 * kGroup * (kThreads - 1)) carries its state from the end of one group to the start of the next
         uint32_t st = 0;
         int last_u = -1;
-        for (uint32_t u = tid; u < full_units; u += kThreads) {
-            uint4 v = *reinterpret_cast<const uint4 *>(grid + 16 * (size_t)u);
-            if (u == 0 && head) {  // zero the bytes in front of the data (leading zeros are free)
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t g0 = tid * kGroup; g0 < full_units; g0 += kThreads * kGroup) {
+            uint4 v[kGroup];
+#pragma unroll
+            for (uint32_t j = 0; j < kGroup; j++)   // (every load is issued before the first one is needed)
+                v[j] = g0 + j < full_units ? *reinterpret_cast<const uint4 *>(grid + 16 * (size_t)(g0 + j))
+                                           : make_uint4(0, 0, 0, 0);
+            if (g0 == 0 && head) {  // zero the bytes in front of the data (leading zeros are free)
+                uint32_t w[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
                 for (uint32_t b = 0; b < head; b++) w[b >> 2] &= ~(0xFFu << (8 * (b & 3)));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                v[0] = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            // s = s * x^(128*(kThreads-1))
             st = tab[kTabMulC + (st & 0xFF)] ^ tab[kTabMulC + 256 + ((st >> 8) & 0xFF)] ^
                  tab[kTabMulC + 512 + ((st >> 16) & 0xFF)] ^ tab[kTabMulC + 768 + (st >> 24)];
-            uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t t = st ^ w4[k];
-                st = tab[768 + (t & 0xFF)] ^ tab[512 + ((t >> 8) & 0xFF)] ^
-                     tab[256 + ((t >> 16) & 0xFF)] ^ tab[t >> 24];
+            for (uint32_t j = 0; j < kGroup; j++) {
+                if (g0 + j < full_units) {
+                    const uint32_t w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t t = st ^ w4[k];
+                        st = tab[768 + (t & 0xFF)] ^ tab[512 + ((t >> 8) & 0xFF)] ^
+                             tab[256 + ((t >> 16) & 0xFF)] ^ tab[t >> 24];
+                    }
+                    last_u = (int)(g0 + j);
+                }
             }
-            last_u = (int)u;
         }
         if (last_u >= 0) {
-            uint32_t behind = full_units - 1 - (uint32_t)last_u;  // units after mine, < kThreads
+            uint32_t behind = full_units - 1 - (uint32_t)last_u;  // units after mine, < kGroup * kThreads
             st = multmodp(st, tables[kTabPow + behind]);
         }
         uint32_t crc = wg_reduce_xor(st, reinterpret_cast<uint32_t *>(red));
@@ -320,10 +334,10 @@ int checksum_tables_create(rsx_engine *e)
             uint32_t prev = t[kTabSlice + (k - 1) * 256 + i];
             t[kTabSlice + k * 256 + i] = (prev >> 8) ^ t[kTabSlice + (prev & 0xFF)];
         }
-    const uint32_t C = xpow8(16ull * (kThreads - 1));
+    const uint32_t C = xpow8(16ull * kGroup * (kThreads - 1));
     for (int k = 0; k < 4; k++)
         for (uint32_t i = 0; i < 256; i++) t[kTabMulC + k * 256 + i] = multmodp(i << (8 * k), C);
-    for (uint32_t j = 0; j < 256; j++) t[kTabPow + j] = xpow8(16ull * j);
+    for (uint32_t j = 0; j < kGroup * 256; j++) t[kTabPow + j] = xpow8(16ull * j);
     t[kTabXSeg] = xpow8(kSeg);
     RSX_HIP(e, hipMalloc(&e->d_crc_tables, kTabWords * sizeof(uint32_t)));
     RSX_HIP(e, hipMemcpy(e->d_crc_tables, t.data(), kTabWords * sizeof(uint32_t),
