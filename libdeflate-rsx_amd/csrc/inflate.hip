@@ -1687,6 +1687,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
 
 constexpr int32_t kStatusPending = -2;    // decoded into tokens, not expanded yet
 constexpr int32_t kStatusFallback = -3;   // left to inflate_kernel
+constexpr int32_t kStatusChain = -5;      // a part that copies from the part in front of it / a stream with such parts
 constexpr uint32_t kTokCap = 96;          // tokens per sub-sequence and round
 constexpr uint32_t kNoTok = 0x100;        // (second kernel) a slot behind a sub-sequence's last token
 constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence in pieces of this many steps
@@ -2112,32 +2113,54 @@ struct __align__(16) ExpandLds {
 #endif
 constexpr uint32_t kXGroupOut = RSX_XGROUP;   // output bytes per group of the second kernel
 static_assert(kLaneBytesStop + 258 <= kXGroupOut && kXGroupOut + 16 <= kXRing, "one sub-sequence fits a group, a group the ring");
+// A stream that was cut into parts whose matches reach across the joints (zlib's sync flush keeps the
+// window) cannot be expanded part beside part, but its tokens are all there: a second launch in which one
+// workgroup takes a whole stream and walks the token rows of its parts one after the other, the ring and
+// the output position running through.
+struct ExpandChain {
+    const uint32_t *parent_first;   // null: every item on its own; else the first part of every stream ...
+    const uint32_t *part_parent;    // ... and the stream of every part
+    const uint64_t *stream_out_off; // the streams' output slots
+    int32_t *stream_status;         // kStatusChain -> RSX_SUCCESS / kStatusFallback
+    uint64_t *stream_out_sizes;
+    uint32_t num_streams;
+    const uint8_t *inner;           // (first launch) per part: it has a part of its own stream in front of it
+};
 __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
     int32_t *__restrict__ status, SplitLayout lay, const uint64_t *__restrict__ in_hi,
-    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p, const uint32_t *__restrict__ count)
+    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p, const uint32_t *__restrict__ count,
+    ExpandChain chain)
 {
     __shared__ ExpandLds L;
     const uint32_t item = blockIdx.x;
-    if (item >= n || (count && item >= *count)) return;
-    if (status[item] != kStatusPending) return;   // (uniform)
+    const bool chained = chain.parent_first != nullptr;   // (uniform)
+    uint32_t seg, seg_end;   // the items whose token rows this workgroup walks
+    uint64_t ob, oe;
+    if (chained) {
+        if (item >= chain.num_streams || chain.stream_status[item] != kStatusChain) return;
+        const uint32_t np = *count;
+        seg = chain.parent_first[item];
+        for (seg_end = seg; seg_end < np && chain.part_parent[seg_end] == item;) seg_end++;
+        ob = chain.stream_out_off[item];
+        oe = chain.stream_out_off[item + 1];
+    } else {
+        if (item >= n || (count && item >= *count)) return;
+        if (status[item] != kStatusPending) return;   // (uniform)
+        seg = item;
+        seg_end = item + 1;
+        ob = out_off[item];
+        oe = out_hi[item];
+    }
     const int tid = threadIdx.x;
-    const uint64_t ib = in_off[item], ie = in_hi[item];
-    const uint64_t ob = out_off[item], oe = out_hi[item];
     StreamCtx c;
     c.in_alloc = in;
     c.in_alloc_len = 0;
     c.out = out + ob;
     c.out_cap = oe - ob;
     c.shift = (uint32_t)((uintptr_t)c.out & 15);
-    // (the first kernel accepted the container: its header is parsed again for the body's place)
-    const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
-    c.body = in + ib + ci.hdr;
-    c.body_len = (ie - ib) - ci.hdr - ci.trailer;
     const uint64_t in_base = *in_base_p;
-    const uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, item) * kT;
-    const RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
     const uint32_t cap = (uint32_t)c.out_cap;
 
     if (tid == 0) {
@@ -2149,7 +2172,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     }
     uint32_t flushed = 0;   // output positions below this are in global memory (uniform)
     uint32_t pos = 0;       // output position reached (uniform)
-    bool bail = false;
+    bool bail = false, reaches_back = false;
     SPLIT_T_BEGIN();
     WG_SYNC();
     auto flush_upto = [&](uint32_t upto_pos) {
@@ -2159,6 +2182,14 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
         flush_range(L, c, flushed, upto);
         flushed = upto;
     };
+    for (; seg < seg_end && !bail; seg++) {
+    const uint64_t ib = in_off[seg], ie = in_hi[seg];
+    // (the first kernel accepted the container: its header is parsed again for the body's place)
+    const ContainerInfo ci = parse_container(format, in + ib, ie - ib);
+    c.body = in + ib + ci.hdr;
+    c.body_len = (ie - ib) - ci.hdr - ci.trailer;
+    const uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, seg) * kT;
+    const RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, seg);
     for (uint64_t r = 0; !bail; r++) {
         unsigned long long tb = SPLIT_T_NOW();
         const RoundRec rec = rounds[r];
@@ -2257,11 +2288,12 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
                         }
                     }
                 }
-                if (err) L.bail = 1;
+                if (err) L.bail = 2;   // (nothing else sets 2; whoever sets 1 beside it loses nothing: both end the item)
             }
             WG_SYNC();
             if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(9, t - tb); tb = t; }
             if (L.bail) {
+                reaches_back = L.bail == 2;
                 bail = true;
                 break;
             }
@@ -2274,10 +2306,18 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
             g0 = g1;
         }
     }
+    }
     if (!bail) flush_range(L, c, flushed, pos);
     if (tid == 0) {
-        status[item] = bail ? kStatusFallback : RSX_SUCCESS;
-        out_sizes[item] = bail ? 0 : pos;
+        if (chained) {
+            chain.stream_status[item] = bail ? kStatusFallback : RSX_SUCCESS;
+            chain.stream_out_sizes[item] = bail ? 0 : pos;
+        } else {
+            // a distance that reaches in front of a part which has a part in front of it may be a good one
+            const bool again = bail && reaches_back && chain.inner && chain.inner[item];
+            status[item] = !bail ? RSX_SUCCESS : again ? kStatusChain : kStatusFallback;
+            out_sizes[item] = bail ? 0 : pos;
+        }
     }
     SPLIT_T_END();
 }
@@ -2479,7 +2519,8 @@ __global__ void part_scatter_kernel(const uint64_t *__restrict__ in_off, uint32_
 __global__ void part_finish_kernel(uint32_t n, const uint32_t *__restrict__ count, const uint64_t *__restrict__ body_hi,
                                    uint64_t *__restrict__ part_lo, const uint32_t *__restrict__ part_parent,
                                    uint64_t *__restrict__ part_hi, uint8_t *__restrict__ part_open,
-                                   int32_t *__restrict__ part_status, uint32_t *__restrict__ parent_first)
+                                   int32_t *__restrict__ part_status, uint32_t *__restrict__ parent_first,
+                                   uint8_t *__restrict__ part_inner)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t np = *count;
@@ -2488,6 +2529,7 @@ __global__ void part_finish_kernel(uint32_t n, const uint32_t *__restrict__ coun
     if (p >= n) {   // (cannot happen: every slot below *count is written by part_scatter_kernel)
         part_hi[s] = part_lo[s] = 0;
         part_open[s] = 0;
+        part_inner[s] = 0;
         part_status[s] = kStatusSkip;
         return;
     }
@@ -2496,7 +2538,9 @@ __global__ void part_finish_kernel(uint32_t n, const uint32_t *__restrict__ coun
     part_hi[s] = bh == kNoBody ? part_lo[s] : last ? bh : part_lo[s + 1];
     part_open[s] = last ? 0 : 1;
     part_status[s] = bh == kNoBody ? kStatusFallback : kStatusPending;   // (the first kernel overwrites it)
-    if (s == 0 || part_parent[s - 1] != p) parent_first[p] = s;
+    const bool first = s == 0 || part_parent[s - 1] != p;
+    part_inner[s] = first ? 0 : 1;
+    if (first) parent_first[p] = s;
 }
 
 // Behind the first kernel, per stream: every part must have decoded, every part but the last must have
@@ -2559,18 +2603,24 @@ __global__ void part_reduce_kernel(const uint64_t *__restrict__ in_off, uint32_t
     body_end[p] = 0;
     if (status[p] != kStatusPending) return;   // (already marked for inflate_kernel)
     const uint32_t np = *count;
-    bool ok = true;
+    bool ok = true, reaches_back = false;
     uint64_t total = 0;
     uint32_t last = parent_first[p];
     for (uint32_t s = last; s < np && part_parent[s] == p; s++) {
-        if (part_status[s] != RSX_SUCCESS) ok = false;
+        if (part_status[s] == kStatusChain) reaches_back = true;
+        else if (part_status[s] != RSX_SUCCESS) ok = false;
         total += part_sizes[s];
         last = s;
     }
-    if (ok) {
+    if (ok && !reaches_back) {
         status[p] = RSX_SUCCESS;
         out_sizes[p] = total;
         body_end[p] = (part_lo[last] - in_off[p]) + part_used[last];
+    } else if (ok) {
+        // parts that copy from the parts in front of them: the stream is expanded again, by one workgroup
+        status[p] = kStatusChain;
+        body_end[p] = (part_lo[last] - in_off[p]) + part_used[last];
+        atomicAdd(taken_out, 1u);
     } else {
         status[p] = kStatusFallback;
         atomicAdd(taken_out, 1u);
@@ -2615,7 +2665,7 @@ static size_t inflate_parts_ws_bytes(size_t n, uint32_t ntiles)
 {
     const size_t cap = n + ntiles;
     return 3 * align_up(n * 8, 256) + align_up(ntiles * 8, 256) + 3 * align_up((ntiles + 1) * 4, 256) + 256 +
-           7 * align_up(cap * 8, 256) + 2 * align_up(cap * 4, 256) + align_up(cap, 256);
+           7 * align_up(cap * 8, 256) + 2 * align_up(cap * 4, 256) + 2 * align_up(cap, 256);
 }
 
 size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool split)
@@ -2676,7 +2726,8 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         uint32_t *part_parent = take32(cap);
         int32_t *part_status = reinterpret_cast<int32_t *>(take32(cap));
         uint8_t *part_open = static_cast<uint8_t *>(ws_take(e, cap));
-        if (!body_lo || !body_hi || !tile_first || !parent_first || !tile_item || !tile_flag || !tile_pre || !count ||
+        uint8_t *part_inner = static_cast<uint8_t *>(ws_take(e, cap));
+        if (!part_inner ||!body_lo || !body_hi || !tile_first || !parent_first || !tile_item || !tile_flag || !tile_pre || !count ||
             !part_lo || !part_hi || !part_olo || !part_ohi || !part_used || !part_bytes || !part_sizes || !part_parent ||
             !part_status || !part_open) {
             e->err = "workspace exhausted";
@@ -2692,7 +2743,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                                                                          tile_first, tile_item, tile_flag, tile_pre,
                                                                          part_lo, part_parent);
         part_finish_kernel<<<(pgrid + tb - 1) / tb, tb, 0, e->stream>>>(grid, count, body_hi, part_lo, part_parent, part_hi,
-                                                                        part_open, part_status, parent_first);
+                                                                        part_open, part_status, parent_first, part_inner);
         // the parts are raw DEFLATE items given as slices; their token rows are laid out by their own numbers
         inflate_decode_kernel<<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, total_in,
                                                            part_status, part_used, lay, part_hi, in_off,
@@ -2702,10 +2753,14 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                                                                       part_status, part_olo, part_ohi, status, count + 1);
         inflate_expand_kernel<<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
                                                            part_sizes, part_status, lay, part_hi, part_ohi, in_off,
-                                                           count);
+                                                           count, ExpandChain{nullptr, nullptr, nullptr, nullptr, nullptr, 0, part_inner});
         part_reduce_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(in_off, grid, count, parent_first, part_parent,
                                                                        part_lo, part_used, part_status, part_sizes,
                                                                        out_sizes, status, body_end, count + 2);
+        // streams whose parts copy across the joints: one workgroup per stream walks the parts' token rows
+        inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
+                                                          part_sizes, part_status, lay, part_hi, part_ohi, in_off,
+                                                          count, ExpandChain{parent_first, part_parent, out_off, status, out_sizes, grid, nullptr});
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
                                                           in_base_p);
@@ -2713,7 +2768,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
                                                           in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
         inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
-                                                          lay, in_hi, out_hi, in_base_p, nullptr);
+                                                          lay, in_hi, out_hi, in_base_p, nullptr, ExpandChain{});
         // whatever the two left (damaged streams, slots that are too small, streams that need more
         // token space than the workspace has) is decoded again by the one-kernel decoder
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,

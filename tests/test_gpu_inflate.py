@@ -298,9 +298,10 @@ def test_large_streams_are_cut_into_parts(rsx, eng):
     assert list(status) == [0] and got[0] == data and eng.last_parts() > 8 and eng.last_whole() == 0
 
 
-def test_parts_with_history_across_the_joint_fall_back(rsx, eng):
+def test_parts_with_history_across_the_joint(rsx, eng):
     # zlib's Z_SYNC_FLUSH keeps the window: matches behind the joint reach in front of it, so the parts cannot
-    # be expanded side by side; Z_FULL_FLUSH forgets it.  Either way the bytes are zlib's.
+    # be expanded side by side (their tokens are expanded by one workgroup per stream, part after part);
+    # Z_FULL_FLUSH forgets it.  Either way the bytes are zlib's.
     data = corpus.text(2 << 20, 21)
     for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
