@@ -2126,6 +2126,7 @@ struct ExpandChain {
     uint32_t num_streams;
     const uint8_t *inner;           // (first launch) per part: it has a part of its own stream in front of it
 };
+template <bool kChained>   // (two kernels by name: the profiler's statistics keep their launches apart)
 __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_sizes,
@@ -2135,7 +2136,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
 {
     __shared__ ExpandLds L;
     const uint32_t item = blockIdx.x;
-    const bool chained = chain.parent_first != nullptr;   // (uniform)
+    constexpr bool chained = kChained;
     uint32_t seg, seg_end;   // the items whose token rows this workgroup walks
     uint64_t ob, oe;
     if (chained) {
@@ -2751,24 +2752,24 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         part_place_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(out_off, grid, count, parent_first, part_parent,
                                                                       part_lo, part_hi, part_used, part_bytes,
                                                                       part_status, part_olo, part_ohi, status, count + 1);
-        inflate_expand_kernel<<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
-                                                           part_sizes, part_status, lay, part_hi, part_ohi, in_off,
-                                                           count, ExpandChain{nullptr, nullptr, nullptr, nullptr, nullptr, 0, part_inner});
+        inflate_expand_kernel<false><<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
+                                                                  part_sizes, part_status, lay, part_hi, part_ohi, in_off,
+                                                                  count, ExpandChain{nullptr, nullptr, nullptr, nullptr, nullptr, 0, part_inner});
         part_reduce_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(in_off, grid, count, parent_first, part_parent,
                                                                        part_lo, part_used, part_status, part_sizes,
                                                                        out_sizes, status, body_end, count + 2);
         // streams whose parts copy across the joints: one workgroup per stream walks the parts' token rows
-        inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
-                                                          part_sizes, part_status, lay, part_hi, part_ohi, in_off,
-                                                          count, ExpandChain{parent_first, part_parent, out_off, status, out_sizes, grid, nullptr});
+        inflate_expand_kernel<true><<<grid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, out, part_olo,
+                                                                part_sizes, part_status, lay, part_hi, part_ohi, in_off,
+                                                                count, ExpandChain{parent_first, part_parent, out_off, status, out_sizes, grid, nullptr});
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
                                                           in_base_p);
     } else if (split) {
         inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
                                                           in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
-        inflate_expand_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
-                                                          lay, in_hi, out_hi, in_base_p, nullptr, ExpandChain{});
+        inflate_expand_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
+                                                                 lay, in_hi, out_hi, in_base_p, nullptr, ExpandChain{});
         // whatever the two left (damaged streams, slots that are too small, streams that need more
         // token space than the workspace has) is decoded again by the one-kernel decoder
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
