@@ -90,7 +90,10 @@ constexpr uint32_t kMaxCuts = kChunk / kSegment + kMaxBlocks;
 constexpr uint32_t kScratchPad = 1024;          // chunk scratch = chunk_len + kScratchPad (a stored block costs 5-6 bytes more than its data, a chunk has at most kMaxBlocks)
 // LDS copy of the input around the current batch: 32 KiB of history, the batch, and
 // the longest match behind it; slid forward kInSlide bytes at a time
-constexpr uint32_t kInSlide = 4096;
+#ifndef RSX_IN_SLIDE
+#define RSX_IN_SLIDE 8192
+#endif
+constexpr uint32_t kInSlide = RSX_IN_SLIDE;
 constexpr uint32_t kInBuf = kWindow + kInSlide + 2048;
 
 __constant__ uint16_t k_len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,
