@@ -1850,6 +1850,11 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
         if (total == 0) break;
         if (RSX_SPLIT_TIMERS && tid == 64) SPLIT_T_ADD(7, 1);
         if (need) L.tspec.work[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)tid;
+        // A sub-sequence that is decoded again is decoded by another thread, often of another wave, and its
+        // tokens go to the same words of global memory: the stores of the pass before must have arrived
+        // before this pass's are sent, or an old token could land on a new one (the barrier orders the
+        // waves' instructions, not their stores in flight).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_SYNC();
         if ((uint32_t)tid < total) {
             const uint32_t i = L.tspec.work[tid];
@@ -1917,6 +1922,11 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
             if (L.final_block) L.status = RSX_SUCCESS;
         }
     }
+    // The sub-sequences behind the one that ends the round have stored tokens too, into rows that the next
+    // round takes for its own: their stores must have arrived before the next round's are sent (by then
+    // they have had the passes and the round's tail to do so: the wait costs nothing, but without it an old
+    // token could land on a new one).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_SYNC();
     if (RSX_SPLIT_TIMERS && tid == 64) { SPLIT_T_ADD(5, SPLIT_T_NOW() - tq); SPLIT_T_ADD(6, 1); }
     return kHdrRows + mx;
@@ -2025,8 +2035,15 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         }
         if (st0 < 0 && stored0 < 0) {
             if (b0 + sub_bits + 64 > DecodeLds::kWinLimitBits) continue;
-            // room for the longest round of tokens (asked only where tokens follow: a stored block needs no rows)
-            if (row + kTokCap + kHdrRows > row_budget) {
+            // room for the longest round of tokens (asked only where tokens follow: a stored block needs no rows).
+            // A token is at least one bit long and starts inside its sub-sequence: short sub-sequences (the
+            // length adapts to streams of few, long matches) need few rows, and the streams that have them
+            // are the short ones that own few.
+            // A stream that runs short of rows goes on with shorter sub-sequences (a round then needs few rows
+            // at worst, and uses fewer).
+            while (row + kHdrRows + min(kTokCap, sub_bits + 1) > row_budget && sub_bits > kDecSubMin)
+                sub_bits = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);   // about half, an odd multiple of 32 bits
+            if (row + kHdrRows + min(kTokCap, sub_bits + 1) > row_budget) {
                 bail = true;
                 break;
             }
@@ -2041,10 +2058,12 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         }
         const int st = L.status;
         const int32_t stored = L.stored_len;
+        // (read in front of the barrier: behind it the first thread moves L.bitpos on, and a wave that saw the
+        // new value would find the block longer than what is left of the body and leave the loop alone)
+        const uint64_t src_byte = L.bitpos >> 3;
         WG_SYNC();
         if (st < 0 && stored >= 0) {
             // stored block body (src/decompress/mod.rs:305-346): the expander copies it
-            const uint64_t src_byte = L.bitpos >> 3;
             if ((uint64_t)stored > c.body_len - src_byte) {
                 bail = true;   // ShortInput
                 break;
@@ -2291,6 +2310,10 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
                 }
                 if (err) L.bail = 2;   // (nothing else sets 2; whoever sets 1 beside it loses nothing: both end the item)
             }
+            // (the bytes that the group before flushed to the output are read back by this group's far
+            // matches, by other waves than the ones that stored them: every wave's stores have arrived
+            // before anyone passes this barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             WG_SYNC();
             if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(9, t - tb); tb = t; }
             if (L.bail) {

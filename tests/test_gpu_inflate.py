@@ -111,6 +111,31 @@ def test_far_matches_and_window_edges(eng):
     check_against_oracle(eng, streams, [len(d)] * 2, 0)
 
 
+def test_stored_block_longer_than_the_rest_of_the_stream(eng):
+    # zlib sends the first pass over a random block as a stored block and everything behind it as matches
+    # at one distance: the stored block is longer than the rest of the body, and the Huffman block behind it
+    # is a run of identical tokens in which every bit offset is a plausible token start
+    streams, caps = [], []
+    for period, seed in ((20000, 1), (20000, 2), (16500, 3), (30000, 4)):
+        rs = np.random.RandomState(seed)
+        block = rs.randint(0, 256, size=period, dtype=np.uint8).tobytes()
+        d = (block * (400000 // period + 1))[:400000]
+        streams += [zlib.compress(d, 6)] * 24
+        caps += [len(d)] * 24
+    check_against_oracle(eng, streams, caps, 1)
+
+
+def test_streams_that_compress_a_thousandfold(eng):
+    # few, long matches: such a stream owns few token rows and gets by with short sub-sequences
+    streams, caps = [], []
+    for d in (bytes(1 << 20), b"\xAB" * 700001, b"abcd" * 200000, corpus.periodic(100, 1 << 20),
+              corpus.periodic(258, 500000), corpus.text(3000, 9) * 300):
+        for lvl in (1, 6, 9):
+            streams.append(zlib.compress(d, lvl))
+            caps.append(len(d))
+    check_against_oracle(eng, streams, caps, 1)
+
+
 def test_error_codes_match_oracle(eng):
     t = corpus.text(50000, 8)
     c = o.compress(t, 6)

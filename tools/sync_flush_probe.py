@@ -1,11 +1,13 @@
 """Times the decoder on streams that zlib cut with Z_SYNC_FLUSH (matches reach across the joints, as in pigz's
 default output): one 64 MiB stream, and 1024 copies of a 1 MiB stream (GPU box, from the repo root).
 RSX_INFLATE_WHOLE=1 shows the same without cutting."""
+import os
 import sys
 import time
 import zlib
 
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(_ROOT, "tests")); sys.path.insert(0, _ROOT)
 import numpy as np
 import torch
 
