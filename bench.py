@@ -255,6 +255,7 @@ def bench_decompress(args, ctx):
 
     dt, k_ms = timed_steps(ctx, step, args.steps, args.warmup)
     ok = verify_rows(ctx, d_out, n, buf, texts, idx, d_status, d_sizes)
+    decoded_twice = ctx.eng.last_fallbacks()   # streams the one-kernel decoder took behind the two-kernel one
     job_bytes = ctx.sum_over_ranks(total_in + total_out)
     alg_bytes = total_in + total_out   # per launch on this rank
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -268,7 +269,7 @@ def bench_decompress(args, ctx):
             "compressor": ("CPU restatement of the reference, 256 KiB sync-flushed segments"
                            if args.compressor == "reference" else "zlib, one stream without joints"),
             "parallelism": "batch sharded over %d GPU(s), no data-path collective" % ctx.world,
-            "verified": ok, "verified_rows": n,
+            "verified": ok, "verified_rows": n, "streams_decoded_twice": decoded_twice,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -97,6 +97,14 @@ float rsx_engine_last_kernel_ms(rsx_engine *e);
 uint32_t rsx_engine_last_parts(rsx_engine *e);
 /* ... and how many of its streams were decoded as a whole after all because a part of them did not stand by itself */
 uint32_t rsx_engine_last_whole(rsx_engine *e);
+/*
+ * Number of streams of the most recent decompress call that the one-kernel decoder took behind the
+ * two-kernel one: damaged streams, slots that are too small, streams cut into parts that did not
+ * stand by themselves, and anything else the fast path gave up (a valid stream in a large enough
+ * slot that shows up here is decoded correctly, but twice).  Diagnostic with no counterpart in the
+ * reference; synchronises.
+ */
+uint32_t rsx_engine_last_fallbacks(rsx_engine *e);
 
 /* Compressor::{deflate,zlib,gzip}_compress_bound, src/compress/mod.rs:2236-2246 */
 uint64_t rsx_compress_bound(int format, uint64_t len);

@@ -12,6 +12,7 @@ int ws_reserve(rsx_engine *e, size_t bytes)
 {
     e->ws_used = 0;
     e->d_last_parts = nullptr;   // (points into the workspace this call carves anew)
+    e->d_last_fallbacks = nullptr;
     e->arena = e->ws;
     e->arena_size = e->ws_size;
     if (bytes <= e->ws_size) return RSX_OK;
@@ -39,6 +40,7 @@ int ws_use_static(rsx_engine *e, size_t bytes)
 {
     e->ws_used = 0;
     e->d_last_parts = nullptr;
+    e->d_last_fallbacks = nullptr;
     e->arena = e->static_scratch;
     e->arena_size = e->static_scratch_size;
     if (!e->static_scratch || bytes > e->static_scratch_size) {
@@ -203,6 +205,17 @@ uint32_t rsx_engine_last_whole(rsx_engine *e)
 {
     uint32_t v[3];
     return last_part_words(e, v) ? v[1] + v[2] : 0;
+}
+
+uint32_t rsx_engine_last_fallbacks(rsx_engine *e)
+{
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->d_last_fallbacks) return 0;
+    DeviceGuard g(e->device);
+    uint32_t v = 0;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return 0;
+    return hipMemcpy(&v, e->d_last_fallbacks, sizeof v, hipMemcpyDeviceToHost) == hipSuccess ? v : 0;
 }
 
 uint64_t rsx_compress_bound(int format, uint64_t len)

@@ -39,6 +39,7 @@ struct rsx_engine {
     // constant tables in device memory (built once in rsx_engine_create)
     uint32_t *d_crc_tables = nullptr;  // see checksum.hip for the layout
 
+    const uint32_t *d_last_fallbacks = nullptr;   // device word: streams of the last decompress call the one-kernel decoder took
     const uint32_t *d_last_parts = nullptr;   // device word: parts of the last decompress call (in the workspace)
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;

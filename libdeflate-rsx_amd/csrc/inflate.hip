@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
     unsigned long long *__restrict__ stats, int only_status, const uint64_t *__restrict__ in_hi,
-    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p)
+    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p, uint32_t *__restrict__ taken)
 {
     unsigned long long tS = 0, tH = 0, tD = 0, tC = 0, tF = 0, t0 = 0, nRounds = 0;
 #define STAT_BEGIN() do { if (STATS) t0 = clock64(); } while (0)
@@ -1488,6 +1488,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     // only_status != 0: this launch only takes the streams another kernel has marked with it (uniform)
     if (only_status && status[item] != only_status) return;
     const int tid = threadIdx.x;
+    if (taken && tid == 0) atomicAdd(taken, 1u);   // (streams this launch decodes: the ones the two kernels left)
 
     // item i is in[in_off[i], in_hi[i]) -> out[out_off[i], out_hi[i]); in_hi = in_off + 1 and
     // out_hi = out_off + 1 for the usual prefix arrays
@@ -1791,8 +1792,9 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
 
 // One round of the first kernel: all lanes decode the Huffman block body in the staged window from
 // L.bitpos on, sub-sequences of `sub_bits` bits, and leave the tokens in this round's rows.  Returns
-// (uniform) the number of rows the round used, header row included, or 0 when it must not be recorded
-// (an error: L.status is set).  *sub_next receives the sub-sequence length to use for the next round.
+// (uniform) the number of rows the round used, header row included, or 0 when it is not to be recorded and
+// L.bitpos stands where it stood (the round is to be decoded again with sub-sequences of *sub_next bits).
+// *sub_next receives the sub-sequence length to use for the next round.
 __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_t win_bit0, uint32_t sub_bits,
                                         uint32_t *__restrict__ rows, uint32_t *nlanes_ret, uint32_t *sub_next,
                                         uint32_t *bytes_ret)
@@ -1910,6 +1912,18 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
         if (last_exit & kExitFull) s = min(s, sub_bits / 2);
         s = max(s, kDecSubMin);
         *sub_next = (((s >> 5) - 1) | 1u) << 5;   // the largest odd multiple of 32 that is not above it
+    }
+    // A sub-sequence near the round's front that ran into the token or byte limit ends the round there: the
+    // round would own a full set of rows for a few sub-sequences' worth of input.  It is not recorded; the
+    // caller decodes from the same place again with sub-sequences half as long (dense stretches are rare:
+    // the length follows the stream's average, and a short stream has few rows to waste).
+    if ((last_exit & kExitFull) && sub_bits > kDecSubMin && (last + 1) * 4 < n_active) {
+        *sub_next = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);
+        *nlanes_ret = 0;
+        *bytes_ret = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next attempt stores to the same rows)
+        WG_SYNC();
+        return 0;
     }
     *nlanes_ret = last + 1;
     *bytes_ret = by;
@@ -2052,6 +2066,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
                                                       &round_bytes);
             produced += round_bytes;
             sub_bits = sub_next;
+            if (used == 0) continue;   // (not recorded: again with shorter sub-sequences)
             if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, 0};
             row += used;
             nrounds++;
@@ -2671,7 +2686,7 @@ int inflate_static_scratch(rsx_engine *e)
 static size_t inflate_common_ws_bytes(size_t n, uint64_t total_out)
 {
     return align_up(n * sizeof(uint64_t), 256) + align_up(n * sizeof(uint32_t), 256) +
-           checksum_ws_bytes(n, total_out) + 1024;
+           checksum_ws_bytes(n, total_out) + 256 + 1024;   // (256: the counter of streams decoded twice)
 }
 
 // Number of tiles the input is searched in for cuts, 0 when the batch is decoded stream by stream: cutting
@@ -2735,6 +2750,17 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         return RSX_E_NOMEM;
     }
     const uint32_t grid = (uint32_t)n;
+    // how many streams the one-kernel decoder takes behind the two (rsx_engine_last_fallbacks)
+    uint32_t *taken = split ? static_cast<uint32_t *>(ws_take(e, 256)) : nullptr;
+    e->d_last_fallbacks = nullptr;
+    if (split) {
+        if (!taken) {
+            e->err = "workspace exhausted";
+            return RSX_E_NOMEM;
+        }
+        RSX_HIP(e, hipMemsetAsync(taken, 0, sizeof(uint32_t), e->stream));
+        e->d_last_fallbacks = taken;
+    }
     (void)hipEventRecord(e->ev_begin, e->stream);
     e->d_last_parts = nullptr;
     if (ntiles) {
@@ -2787,7 +2813,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                                                                 count, ExpandChain{parent_first, part_parent, out_off, status, out_sizes, grid, nullptr});
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
-                                                          in_base_p);
+                                                          in_base_p, taken);
     } else if (split) {
         inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
                                                           in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
@@ -2797,12 +2823,12 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         // token space than the workspace has) is decoded again by the one-kernel decoder
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
-                                                          in_base_p);
+                                                          in_base_p, taken);
     } else if (e->inflate_stats) {
         unsigned long long *d_stats = nullptr;   // (development aid: allocates and synchronises)
         RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
         inflate_kernel<true><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                         status, body_end, d_stats, 0, in_hi, out_hi, in_base_p);
+                                                         status, body_end, d_stats, 0, in_hi, out_hi, in_base_p, nullptr);
         (void)hipEventRecord(e->ev_end, e->stream);
         std::vector<unsigned long long> h(n * 12);
         RSX_HIP(e, hipMemcpy(h.data(), d_stats, h.size() * 8, hipMemcpyDeviceToHost));
@@ -2820,7 +2846,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                 (double)sum[11] / n);
     } else {
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                          status, body_end, nullptr, 0, in_hi, out_hi, in_base_p);
+                                                          status, body_end, nullptr, 0, in_hi, out_hi, in_base_p, nullptr);
     }
     if (split || !e->inflate_stats) (void)hipEventRecord(e->ev_end, e->stream);
 #if RSX_SPLIT_TIMERS

@@ -26,6 +26,7 @@ SYMBOLS = [
     ("rsx_engine_last_kernel_ms", C.c_float, [_P]),
     ("rsx_engine_last_parts", C.c_uint32, [_P]),
     ("rsx_engine_last_whole", C.c_uint32, [_P]),
+    ("rsx_engine_last_fallbacks", C.c_uint32, [_P]),
     ("rsx_compress_bound", C.c_uint64, [C.c_int, C.c_uint64]),
     ("rsx_batch_compress", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_compress_flush", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
@@ -126,6 +127,10 @@ class Engine:
     def last_whole(self):
         """Streams of the last decompress call that were decoded as a whole after a part of them failed."""
         return int(self._lib.rsx_engine_last_whole(self._h))
+
+    def last_fallbacks(self):
+        """Streams of the last decompress call that the one-kernel decoder took behind the two-kernel one."""
+        return int(self._lib.rsx_engine_last_fallbacks(self._h))
 
     # ---- host-pointer calls (numpy) -------------------------------------------------
 

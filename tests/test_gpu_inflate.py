@@ -122,7 +122,9 @@ def test_stored_block_longer_than_the_rest_of_the_stream(eng):
         d = (block * (400000 // period + 1))[:400000]
         streams += [zlib.compress(d, 6)] * 24
         caps += [len(d)] * 24
-    check_against_oracle(eng, streams, caps, 1)
+    for _ in range(3):
+        check_against_oracle(eng, streams, caps, 1)
+        assert eng.last_fallbacks() == 0   # (decoded once: no stream was handed to the one-kernel decoder)
 
 
 def test_streams_that_compress_a_thousandfold(eng):
@@ -134,6 +136,36 @@ def test_streams_that_compress_a_thousandfold(eng):
             streams.append(zlib.compress(d, lvl))
             caps.append(len(d))
     check_against_oracle(eng, streams, caps, 1)
+    assert eng.last_fallbacks() == 0
+
+
+def test_valid_streams_are_decoded_once(eng):
+    # the one-kernel decoder behind the two-kernel one is for damaged streams and small slots: a batch of
+    # valid streams of every kind must not need it (a stream that does is right, but slow)
+    datas = [corpus.text(300000, 21), corpus.mixed(400000, 22), corpus.json_like(200000, 23), corpus.random_bytes(70000, 24),
+             bytes(100000), b"a", b"", b"ab" * 5000, corpus.text(5000, 25)]
+    for fmt in (0, 1, 2):
+        streams, caps = [], []
+        for lvl in (1, 6, 9):
+            for d in datas:
+                z = o.compress(d, lvl, fmt)
+                if z is not None:   # (an input the reference's compressor refuses)
+                    streams.append(z)
+                    caps.append(len(d))
+        if fmt:
+            for d in datas:
+                for lvl in (0, 1, 6, 9):
+                    co = zlib.compressobj(lvl, zlib.DEFLATED, WBITS[fmt])
+                    streams.append(co.compress(d) + co.flush())
+                    caps.append(len(d) + 7)
+        check_against_oracle(eng, streams, caps, fmt)
+        assert eng.last_fallbacks() == 0, fmt
+    # ... and the counter counts: one damaged stream, one slot that is too small
+    good = zlib.compress(datas[0], 6)
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x55
+    check_against_oracle(eng, [good, bytes(bad), good], [len(datas[0]), len(datas[0]), 1000], 1)
+    assert eng.last_fallbacks() == 2
 
 
 def test_error_codes_match_oracle(eng):

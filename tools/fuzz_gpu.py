@@ -179,7 +179,7 @@ def fuzz_parts(eng, budget, seed, max_seeds=1 << 30):
 
 def fuzz_inflate(eng, budget, seed, max_seeds=1 << 30):
     t0 = time.time()
-    total = displaced = 0
+    total = displaced = twice = 0
     last = seed + max_seeds
     while time.time() - t0 < budget and seed < last:
         rs = np.random.RandomState(seed)
@@ -217,8 +217,11 @@ def fuzz_inflate(eng, budget, seed, max_seeds=1 << 30):
                     caps.append(len(d))
         caps = [max(0, c) for c in caps]
         got, status = eng.batch_decompress(streams, caps, fmt)
+        valid = []
         for i, s in enumerate(streams):
             r, _, want = o.decompress(s, caps[i], fmt)
+            if r == o.SUCCESS:
+                valid.append(i)
             if int(status[i]) != r or (r == o.SUCCESS and got[i] != want):
                 if fmt != 0 and trailer_is_displaced(s, fmt):
                     displaced += 1   # the one documented divergence: where the trailer is looked for
@@ -228,9 +231,23 @@ def fuzz_inflate(eng, budget, seed, max_seeds=1 << 30):
                     f.write(s)
                 sys.exit(1)
         total += len(streams)
+        # the streams that decode well, by themselves: none of them should need the one-kernel decoder
+        if valid:
+            eng.batch_decompress([streams[i] for i in valid], [caps[i] for i in valid], fmt)
+            fb = eng.last_fallbacks()
+            if fb:
+                twice += fb
+                for i in valid:
+                    eng.batch_decompress([streams[i]], [caps[i]], fmt)
+                    if eng.last_fallbacks():
+                        print("seed %d item %d fmt %d: a valid stream of %d bytes was decoded twice" % (seed, i, fmt, len(streams[i])))
+                        if twice <= 8:
+                            with open("gpurun_out/fuzz_twice_%d_%d.bin" % (seed, i), "wb") as f:
+                                f.write(streams[i])
         print("seed %d ok (%d streams, fmt %d)" % (seed, len(streams), fmt), flush=True)
         seed += 1
-    print("fuzz ok: %d streams, seeds up to %d, %d with a displaced trailer skipped" % (total, seed - 1, displaced))
+    print("fuzz ok: %d streams, seeds up to %d, %d with a displaced trailer skipped, %d valid streams decoded twice" %
+          (total, seed - 1, displaced, twice))
 
 
 if __name__ == "__main__":
