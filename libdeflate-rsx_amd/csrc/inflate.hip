@@ -1721,7 +1721,7 @@ struct RoundRec {
     uint32_t kind;      // ROUND_*
     uint32_t a;         // tokens: first row (the header row);   stored: length in bytes
     uint32_t b;         // tokens: number of sub-sequences;       stored: low half of the source offset in the body
-    uint32_t c;         //                                        stored: high half
+    uint32_t c;         // tokens: 0, or 1 + the pool row its chunk starts at (a is then relative to the chunk);   stored: high half
 };
 
 // A stream owns one token row per 512 bits of its input (and the longest round on top).  Text whose blocks
@@ -1729,9 +1729,16 @@ struct RoundRec {
 // blocks need one per 550, and one per 1024 sent a third of them to the one-kernel decoder.
 constexpr uint32_t kRowBitsLog2 = 9;
 // where a stream's token rows and round records live (both kernels compute the same)
+constexpr uint32_t kPoolChunk = 256;   // rows a stream takes from the shared pool at a time
 struct SplitLayout {
     uint32_t *tok;          // token rows of all streams
     RoundRec *rounds;       // round records of all streams
+    // Rows behind the streams' own, shared by the batch: a stream that has used up its share (blocks so short
+    // that most rounds fill a few columns of their rows, streams of nothing but literals) takes kPoolChunk rows
+    // at a time from here, first come first served; its round records then say which chunk a round's rows are in.
+    uint64_t pool_first;    // first row of the pool
+    uint32_t pool_rows;     // rows in it
+    unsigned long long *pool_next;   // rows asked for so far (cleared per call; 64 bits: every stream of a batch may ask)
     // rel = the stream's input offset minus the batch's first
     __device__ uint64_t first_row(uint64_t rel, uint32_t item) const
     {
@@ -1742,6 +1749,11 @@ struct SplitLayout {
     __device__ uint64_t round_budget(uint64_t in_len) const { return (in_len >> 8) + 64; }
 };
 static inline uint64_t split_tok_rows(size_t n, uint64_t total_in) { return (total_in * 8 >> kRowBitsLog2) + n * (kTokCap + kHdrRows + 1) + 2; }
+static inline uint64_t split_pool_rows(uint64_t total_in)
+{
+    const uint64_t r = (total_in * 8 >> kRowBitsLog2) / 4;   // a quarter on top of the streams' own rows
+    return r < 1024 ? 1024 : r > 0x7FFFFF00ull ? 0x7FFFFF00ull : r;
+}
 static inline uint64_t split_round_recs(size_t n, uint64_t total_in) { return (total_in >> 8) + n * 66 + 2; }
 
 typedef StreamLdsT<kDecWinBytes, 16> DecodeLds;
@@ -1986,10 +1998,12 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     }
     c.body = in + ib + ci.hdr;
     c.body_len = (ie - ib) - ci.hdr - ci.trailer;
-    uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, item) * kT;
+    uint32_t *tok = lay.tok + lay.first_row(ib - in_base, item) * kT;   // (the stream's own rows, later a chunk of the pool)
     RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
-    const uint64_t row_budget = lay.row_budget(ie - ib), round_budget = lay.round_budget(ie - ib);
+    uint64_t row_budget = lay.row_budget(ie - ib);
+    const uint64_t round_budget = lay.round_budget(ie - ib);
     uint64_t row = 0, nrounds = 0;   // (uniform)
+    uint32_t chunk = 0;              // 0: own rows; else 1 + the pool row the current chunk starts at (uniform)
 
     if (tid == 0) {
         L.bitpos = 0;
@@ -2058,8 +2072,22 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
             while (row + kHdrRows + min(kTokCap, sub_bits + 1) > row_budget && sub_bits > kDecSubMin)
                 sub_bits = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);   // about half, an odd multiple of 32 bits
             if (row + kHdrRows + min(kTokCap, sub_bits + 1) > row_budget) {
-                bail = true;
-                break;
+                // out of rows: on with a chunk of the pool, as long as it lasts
+                if (tid == 0) {
+                    const unsigned long long at64 = lay.pool_next ? atomicAdd(lay.pool_next, (unsigned long long)kPoolChunk) : ~0ull;
+                    L.first_flag = at64 <= lay.pool_rows && lay.pool_rows - at64 >= kPoolChunk ? (uint32_t)at64 : 0xFFFFFFFFu;
+                }
+                WG_SYNC();
+                const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first_flag);   // (the rows' address stays scalar)
+                WG_SYNC();
+                if (at == 0xFFFFFFFFu) {
+                    bail = true;
+                    break;
+                }
+                tok = lay.tok + (lay.pool_first + at) * kT;
+                chunk = at + 1;
+                row = 0;
+                row_budget = kPoolChunk;
             }
             uint32_t nlanes = 0, sub_next = sub_bits, round_bytes = 0;
             const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, tok + row * kT, &nlanes, &sub_next,
@@ -2067,7 +2095,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
             produced += round_bytes;
             sub_bits = sub_next;
             if (used == 0) continue;   // (not recorded: again with shorter sub-sequences)
-            if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, 0};
+            if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, chunk};
             row += used;
             nrounds++;
         }
@@ -2251,7 +2279,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
         }
         // a round of tokens: its sub-sequences go through the ring in groups that fit it
         const uint32_t nlanes = rec.b;
-        const uint32_t *const rows = tok + (uint64_t)rec.a * kT;
+        const uint32_t *const rows = rec.c ? lay.tok + (lay.pool_first + (rec.c - 1) + rec.a) * kT : tok + (uint64_t)rec.a * kT;
         const uint32_t info = (uint32_t)tid < nlanes ? rows[tid] : 0u;
         const uint32_t ntok = info & 0xFF, nm = (info >> 8) & 0xFF, bytes = info >> 16;
         uint32_t exb, exn;
@@ -2713,7 +2741,7 @@ size_t inflate_ws_bytes(size_t n, uint64_t total_in, uint64_t total_out, bool sp
     if (split) {
         const uint32_t ntiles = inflate_part_tiles(n, total_in);
         const size_t items = n + ntiles;
-        b += align_up(split_tok_rows(items, total_in) * kT * sizeof(uint32_t), 256) +
+        b += align_up((split_tok_rows(items, total_in) + split_pool_rows(total_in)) * kT * sizeof(uint32_t), 256) +
              align_up(split_round_recs(items, total_in) * sizeof(RoundRec), 256);
         if (ntiles) b += inflate_parts_ws_bytes(n, ntiles);
     }
@@ -2740,9 +2768,11 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     // streams cut into parts: only for the usual layout (an item's slices could overlap a neighbour's)
     const uint32_t ntiles = split && !slices && e->inflate_parts ? inflate_part_tiles(n, total_in) : 0u;
     const size_t items = n + (split && !slices ? inflate_part_tiles(n, total_in) : 0u);   // (as inflate_ws_bytes counts)
-    SplitLayout lay{nullptr, nullptr};
+    SplitLayout lay{nullptr, nullptr, 0, 0, nullptr};
     if (split) {
-        lay.tok = static_cast<uint32_t *>(ws_take(e, split_tok_rows(items, total_in) * kT * sizeof(uint32_t)));
+        lay.pool_first = split_tok_rows(items, total_in);
+        lay.pool_rows = (uint32_t)split_pool_rows(total_in);
+        lay.tok = static_cast<uint32_t *>(ws_take(e, (lay.pool_first + lay.pool_rows) * kT * sizeof(uint32_t)));
         lay.rounds = static_cast<RoundRec *>(ws_take(e, split_round_recs(items, total_in) * sizeof(RoundRec)));
     }
     if (!body_end || !sums || (split && (!lay.tok || !lay.rounds))) {
@@ -2758,8 +2788,9 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
             e->err = "workspace exhausted";
             return RSX_E_NOMEM;
         }
-        RSX_HIP(e, hipMemsetAsync(taken, 0, sizeof(uint32_t), e->stream));
+        RSX_HIP(e, hipMemsetAsync(taken, 0, 16, e->stream));
         e->d_last_fallbacks = taken;
+        lay.pool_next = reinterpret_cast<unsigned long long *>(taken + 2);
     }
     (void)hipEventRecord(e->ev_begin, e->stream);
     e->d_last_parts = nullptr;

@@ -168,6 +168,32 @@ def test_valid_streams_are_decoded_once(eng):
     assert eng.last_fallbacks() == 2
 
 
+def test_streams_of_short_blocks_borrow_token_rows(eng):
+    # zlib at its default memLevel, every strategy, with and without a flush every 20 KB: rounds end where blocks
+    # end, streams of nothing but literals (Z_HUFFMAN_ONLY) and of short blocks use up their share of the token
+    # rows and go on with rows of the batch's shared pool instead of being decoded again by the one-kernel decoder
+    datas = [corpus.text(300000, 31), corpus.mixed(300000, 32), corpus.json_like(300000, 33), corpus.text(8000, 35)]
+    for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+        for flush in (None, zlib.Z_SYNC_FLUSH, zlib.Z_BLOCK):
+            streams, caps = [], []
+            for d in datas:
+                for lvl in (1, 6):
+                    co = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, strat)
+                    parts = []
+                    step = len(d) if flush is None else 20000
+                    for at in range(0, len(d), step):
+                        parts.append(co.compress(d[at:at + step]))
+                        if flush is not None:
+                            parts.append(co.flush(flush))
+                    parts.append(co.flush())
+                    streams.append(b"".join(parts))
+                    caps.append(len(d))
+            got, status = eng.batch_decompress(streams, caps, 1)
+            assert [int(x) for x in status] == [0] * len(streams)
+            assert got == [d for d in datas for _ in (1, 6)]
+            assert eng.last_fallbacks() == 0, (strat, flush)
+
+
 def test_error_codes_match_oracle(eng):
     t = corpus.text(50000, 8)
     c = o.compress(t, 6)
