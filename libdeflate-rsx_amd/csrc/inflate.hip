@@ -255,6 +255,7 @@ struct __align__(16) StreamLdsT {
     int32_t final_block;
     int32_t stored_len;   // >= 0: a stored block of that many bytes is pending
     int32_t restage;      // header parse wants the window moved first
+    uint32_t pool_chunk;  // (token decoder) 0, or 1 + the row of the shared pool where the stream's current chunk of rows starts
     uint64_t bitpos;      // next unread bit, relative to the start of the DEFLATE body
     SPLIT_T_FIELD
 };
@@ -1804,9 +1805,8 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
 
 // One round of the first kernel: all lanes decode the Huffman block body in the staged window from
 // L.bitpos on, sub-sequences of `sub_bits` bits, and leave the tokens in this round's rows.  Returns
-// (uniform) the number of rows the round used, header row included, or 0 when it is not to be recorded and
-// L.bitpos stands where it stood (the round is to be decoded again with sub-sequences of *sub_next bits).
-// *sub_next receives the sub-sequence length to use for the next round.
+// (uniform) the number of rows the round used, header row included.  *sub_next receives the sub-sequence
+// length to use for the next round, *nlanes_ret the number of sub-sequences in the round.
 __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_t win_bit0, uint32_t sub_bits,
                                         uint32_t *__restrict__ rows, uint32_t *nlanes_ret, uint32_t *sub_next,
                                         uint32_t *bytes_ret)
@@ -1925,19 +1925,8 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
         s = max(s, kDecSubMin);
         *sub_next = (((s >> 5) - 1) | 1u) << 5;   // the largest odd multiple of 32 that is not above it
     }
-    // A sub-sequence near the round's front that ran into the token or byte limit ends the round there: the
-    // round would own a full set of rows for a few sub-sequences' worth of input.  It is not recorded; the
-    // caller decodes from the same place again with sub-sequences half as long (dense stretches are rare:
-    // the length follows the stream's average, and a short stream has few rows to waste).
-    if ((last_exit & kExitFull) && sub_bits > kDecSubMin && (last + 1) * 4 < n_active) {
-        *sub_next = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);
-        *nlanes_ret = 0;
-        *bytes_ret = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next attempt stores to the same rows)
-        WG_SYNC();
-        return 0;
-    }
-    *nlanes_ret = last + 1;
+    // (bit 31: the round ends with a sub-sequence that ran into the token or byte limit)
+    *nlanes_ret = (last + 1) | ((last_exit & kExitFull) ? 0x80000000u : 0u);
     *bytes_ret = by;
     if (tid == 0) {
         L.bitpos = (uint64_t)(win_bit0 + (int64_t)(last_exit & kExitPosMask));
@@ -1998,12 +1987,10 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     }
     c.body = in + ib + ci.hdr;
     c.body_len = (ie - ib) - ci.hdr - ci.trailer;
-    uint32_t *tok = lay.tok + lay.first_row(ib - in_base, item) * kT;   // (the stream's own rows, later a chunk of the pool)
+    uint32_t *const tok = lay.tok + lay.first_row(ib - in_base, item) * kT;   // (the stream's own rows)
     RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
-    uint64_t row_budget = lay.row_budget(ie - ib);
-    const uint64_t round_budget = lay.round_budget(ie - ib);
-    uint64_t row = 0, nrounds = 0;   // (uniform)
-    uint32_t chunk = 0;              // 0: own rows; else 1 + the pool row the current chunk starts at (uniform)
+    const uint64_t own_budget = lay.row_budget(ie - ib), round_budget = lay.round_budget(ie - ib);
+    uint64_t row = 0, nrounds = 0;   // (uniform) row: rows used of the stream's own, or of its current chunk of the pool
 
     if (tid == 0) {
         L.bitpos = 0;
@@ -2012,6 +1999,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         L.final_block = 0;
         L.stored_len = -1;
         L.restage = 0;
+        L.pool_chunk = 0;
     }
     uint32_t sub_bits = kDecSubMax;
     uint64_t seen_bitpos = ~0ull;
@@ -2056,6 +2044,9 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         }
         const int restage = L.restage, st0 = L.status, stored0 = L.stored_len;
         const uint32_t b0 = (uint32_t)((int64_t)L.bitpos - win_bit0);
+        // 0: the stream writes to its own rows; else 1 + the pool row its current chunk starts at (kept in LDS: the
+        // kernel has no register to spare, and it is asked for once per round)
+        uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pool_chunk);
         WG_SYNC();
         if (restage) {
             if (tid == 0) L.restage = 0;
@@ -2063,6 +2054,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         }
         if (st0 < 0 && stored0 < 0) {
             if (b0 + sub_bits + 64 > DecodeLds::kWinLimitBits) continue;
+            uint64_t row_budget = chunk ? (uint64_t)kPoolChunk : own_budget;
             // room for the longest round of tokens (asked only where tokens follow: a stored block needs no rows).
             // A token is at least one bit long and starts inside its sub-sequence: short sub-sequences (the
             // length adapts to streams of few, long matches) need few rows, and the streams that have them
@@ -2073,28 +2065,41 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
                 sub_bits = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);   // about half, an odd multiple of 32 bits
             if (row + kHdrRows + min(kTokCap, sub_bits + 1) > row_budget) {
                 // out of rows: on with a chunk of the pool, as long as it lasts
+                // (everyone has read L.pool_chunk in front of the barrier above)
                 if (tid == 0) {
                     const unsigned long long at64 = lay.pool_next ? atomicAdd(lay.pool_next, (unsigned long long)kPoolChunk) : ~0ull;
-                    L.first_flag = at64 <= lay.pool_rows && lay.pool_rows - at64 >= kPoolChunk ? (uint32_t)at64 : 0xFFFFFFFFu;
+                    const bool got = at64 <= lay.pool_rows && lay.pool_rows - at64 >= kPoolChunk;
+                    L.first_flag = got ? (uint32_t)at64 : 0xFFFFFFFFu;
+                    if (got) L.pool_chunk = (uint32_t)at64 + 1;
                 }
                 WG_SYNC();
-                const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first_flag);   // (the rows' address stays scalar)
+                const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first_flag);
                 WG_SYNC();
                 if (at == 0xFFFFFFFFu) {
                     bail = true;
                     break;
                 }
-                tok = lay.tok + (lay.pool_first + at) * kT;
                 chunk = at + 1;
                 row = 0;
                 row_budget = kPoolChunk;
             }
+            uint32_t *const rows_at = (chunk ? lay.tok + (lay.pool_first + (chunk - 1)) * kT : tok) + row * kT;
             uint32_t nlanes = 0, sub_next = sub_bits, round_bytes = 0;
-            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, tok + row * kT, &nlanes, &sub_next,
-                                                      &round_bytes);
+            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, rows_at, &nlanes, &sub_next, &round_bytes);
+            // A sub-sequence near the round's front that ran into the token or byte limit ends the round there: the
+            // round owns a full set of rows for a few sub-sequences' worth of input.  Where the stream has rows to
+            // spare that is the cheaper way; where it has not (a short stream, the end of a share) the round is not
+            // recorded: the position goes back and the same bits are decoded again with sub-sequences half as long.
+            const bool front_full = (nlanes >> 31) && (nlanes & 0x7FFFFFFFu) * 4 < (uint32_t)kT;
+            nlanes &= 0x7FFFFFFFu;
+            if (front_full && sub_bits > kDecSubMin && row + 2 * (kHdrRows + kTokCap) > row_budget) {
+                sub_bits = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);
+                if (tid == 0) L.bitpos = (uint64_t)(win_bit0 + (int64_t)b0);   // (a round that ends this way changed nothing else)
+                WG_SYNC();
+                continue;
+            }
             produced += round_bytes;
             sub_bits = sub_next;
-            if (used == 0) continue;   // (not recorded: again with shorter sub-sequences)
             if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, chunk};
             row += used;
             nrounds++;
