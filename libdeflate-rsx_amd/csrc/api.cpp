@@ -515,7 +515,21 @@ int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_
         status[i] = RSX_SUCCESS;
         active[i] = i;
     }
+    // One launch chain per member depth.  An item of thousands of tiny members would hold the engine for as many
+    // serial launches while every other item waits: items still unfinished after kMaxMemberRounds members are
+    // reported RSX_BAD_DATA (gzip sets no limit; pigz and concatenated archives stay far below this one).
+    constexpr size_t kMaxMemberRounds = 4096;
+    size_t rounds_done = 0;
+    auto rounds = [&]() -> int {
     while (!active.empty()) {
+        if (rounds_done++ == kMaxMemberRounds) {
+            for (size_t i : active) {
+                status[i] = RSX_BAD_DATA;
+                out_sizes[i] = 0;
+            }
+            active.clear();
+            break;
+        }
         const size_t m = active.size();
         uint64_t max_out = 0;
         for (size_t k = 0; k < m; k++) {
@@ -564,6 +578,17 @@ int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_
             }
         }
         active.swap(next);
+    }
+    return RSX_OK;
+    };
+    r = rounds();
+    if (r != RSX_OK) {
+        // an engine error in the middle: nothing of the items still in flight is usable
+        for (size_t i : active) {
+            status[i] = RSX_INTERNAL_ERROR;
+            out_sizes[i] = 0;
+        }
+        return r;
     }
     for (size_t i = 0; i < n; i++)
         if (status[i] == RSX_SUCCESS && out_sizes[i])

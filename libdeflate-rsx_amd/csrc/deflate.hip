@@ -1874,11 +1874,12 @@ uint64_t chunk_upper_bound(size_t n, uint64_t total_in) { return total_in / kChu
 static uint32_t deflate_grid_bound(uint64_t chunks) { return (uint32_t)(chunks < 1024 ? chunks : 1024); }
 
 // token units per chunk in the token buffer: at most one per byte, and the last 16-byte piece of a
-// batch may end up to 7 units behind them
+// batch may end up to 7 units behind them.  Rounded like the chunk scratch below: a chunk that passes the
+// kernels' guard against an understated max_item (its length fits the scratch stride) then fits here too.
 static uint64_t tok_stride_units(uint64_t max_item)
 {
     const uint64_t longest = max_item < kChunk ? max_item : kChunk;
-    return align_up(longest + 64, 8);
+    return align_up(longest, 256) + 64;
 }
 
 // bytes of scratch per chunk: no chunk is longer than the longest item

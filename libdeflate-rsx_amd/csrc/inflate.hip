@@ -1681,7 +1681,7 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
 // running totals (row p: output bytes | matches << 16 of the first 16 p tokens of every sub-sequence,
 // so that the second kernel can start in the middle of one), and then
 // as many rows as its longest sub-sequence has tokens; row k holds the k-th token of
-// every sub-sequence: a literal's byte, or a match (1 << 31 | distance - 1 << 8 | length - 3).
+// every sub-sequence: a literal's byte, or a match (1 << 31 | length - 3 << 15 | distance - 1).
 // A decoder step that finishes no token (a length still waiting for its distance, a subtable hop,
 // the end of the block) writes nothing.  A row per token of every lane keeps the stores of a wave
 // close together (lanes that are a token apart write neighbouring rows).  Rounds are listed in a
@@ -1691,7 +1691,6 @@ constexpr int32_t kStatusPending = -2;    // decoded into tokens, not expanded y
 constexpr int32_t kStatusFallback = -3;   // left to inflate_kernel
 constexpr int32_t kStatusChain = -5;      // a part that copies from the part in front of it / a stream with such parts
 constexpr uint32_t kTokCap = 96;          // tokens per sub-sequence and round
-constexpr uint32_t kNoTok = 0x100;        // (second kernel) a slot behind a sub-sequence's last token
 constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence in pieces of this many steps
 constexpr uint32_t kSegRows = kTokCap / kSegSteps - 1;   // header rows 1..kSegRows: bytes | matches << 16 in front of piece p
 constexpr uint32_t kHdrRows = 1 + kSegRows;
@@ -1786,7 +1785,7 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
         over = !kEndFar && d.b > end32;
         const bool is_match = kind == kTokMatch;
         const bool fin = kind >= kTokLit && !over;   // a literal or a match ends with this step, inside the body
-        const uint32_t rec = is_match ? (0x80000000u | ((o.value - 1) << 8) | (o.len - 3)) : o.value;
+        const uint32_t rec = is_match ? (0x80000000u | ((o.len - 3) << 15) | (o.value - 1)) : o.value;
         if (fin) col[ntok * kT] = rec;
         ntok += fin ? 1u : 0u;
         bytes += fin ? (is_match ? o.len : 1u) : 0u;
@@ -2131,7 +2130,10 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         if (st >= 0) break;
     }
     if (tid == 0) {
-        const bool ok = !bail && L.status == RSX_SUCCESS;
+        // A part that has another part of its stream behind it must end between two blocks with more blocks to
+        // come: a final block that happens to end exactly at the joint ends the STREAM there (the bytes behind it
+        // are not part of it, src/decompress/mod.rs:246-249), which only the one-kernel decoder can report.
+        const bool ok = !bail && L.status == RSX_SUCCESS && !(open_end && L.final_block);
         if (ok) rounds[nrounds] = RoundRec{ROUND_END, 0, 0, 0};
         status[item] = ok ? kStatusPending : kStatusFallback;
         body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
@@ -2333,27 +2335,28 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
                     const uint32_t *col = rows + (kHdrRows + p * kSegSteps) * kT + l;
                     uint32_t t16[kSegSteps];
 #pragma unroll
-                    for (uint32_t j = 0; j < kSegSteps; j++) t16[j] = j < nslot ? col[j * kT] : kNoTok;
+                    for (uint32_t j = 0; j < kSegSteps; j++) t16[j] = j < nslot ? col[j * kT] : 0u;
                     const uint32_t before = p ? rows[p * kT + l] : 0u;
                     uint32_t op = round_start + (L.lane_at[l] - bb) + (before & 0xFFFF);
                     uint32_t mi = L.lane_mi[l] - bn + (before >> 16);
+                    // A literal and a match both leave the token's low byte where they start (the literal itself,
+                    // or the low half of distance - 1), so the common part of a step has no select; what only a
+                    // match does stands behind one test.
 #pragma unroll
                     for (uint32_t j = 0; j < kSegSteps; j++) {
                         const uint32_t t = t16[j];
-                        if (t == kNoTok) continue;
-                        if ((int32_t)t < 0) {
-                            const uint32_t len = (t & 0xFF) + 3, d1 = (t >> 8) & 0x7FFF;
+                        const bool act = j < nslot, is_m = (int32_t)t < 0;   // (slots behind the last token hold 0)
+                        const uint32_t at = op + c.shift;
+                        if (act) L.ring[at & kXRingMask] = (uint8_t)t;
+                        if (is_m) {
+                            const uint32_t d1 = t & 0x7FFF;
                             err = err || d1 >= op;   // the distance reaches in front of the output
                             L.mq.dst[mi] = (uint16_t)(op - round_start);
-                            L.ring[(op + c.shift) & kXRingMask] = (uint8_t)d1;
-                            L.ring[(op + c.shift + 1) & kXRingMask] = (uint8_t)(d1 >> 8);
-                            L.ring[(op + c.shift + 2) & kXRingMask] = (uint8_t)(len - 3);
-                            op += len;
-                            mi++;
-                        } else {
-                            L.ring[(op + c.shift) & kXRingMask] = (uint8_t)t;
-                            op++;
+                            L.ring[(at + 1) & kXRingMask] = (uint8_t)(d1 >> 8);
+                            L.ring[(at + 2) & kXRingMask] = (uint8_t)(t >> 15);
                         }
+                        op += is_m ? ((t >> 15) & 0xFF) + 3 : act ? 1u : 0u;
+                        mi += is_m ? 1u : 0u;
                     }
                 }
                 if (err) L.bail = 2;   // (nothing else sets 2; whoever sets 1 beside it loses nothing: both end the item)
@@ -2785,6 +2788,9 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         return RSX_E_NOMEM;
     }
     const uint32_t grid = (uint32_t)n;
+    // the per-stream timers of RSX_INFLATE_STATS allocate and synchronise: never on the static scratch, whose
+    // callers must not allocate
+    const bool stats = !split && e->inflate_stats && e->arena != e->static_scratch;
     // how many streams the one-kernel decoder takes behind the two (rsx_engine_last_fallbacks)
     uint32_t *taken = split ? static_cast<uint32_t *>(ws_take(e, 256)) : nullptr;
     e->d_last_fallbacks = nullptr;
@@ -2860,7 +2866,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
                                                           in_base_p, taken);
-    } else if (e->inflate_stats) {
+    } else if (stats) {
         unsigned long long *d_stats = nullptr;   // (development aid: allocates and synchronises)
         RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
         inflate_kernel<true><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
@@ -2884,7 +2890,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, 0, in_hi, out_hi, in_base_p, nullptr);
     }
-    if (split || !e->inflate_stats) (void)hipEventRecord(e->ev_end, e->stream);
+    if (!stats) (void)hipEventRecord(e->ev_end, e->stream);
 #if RSX_SPLIT_TIMERS
     if (split) {
         unsigned long long t[24], z[24] = {0};

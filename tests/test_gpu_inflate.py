@@ -422,6 +422,39 @@ def test_parts_and_false_joints(rsx, eng):
     assert eng.last_parts() > len(streams)
 
 
+def test_final_block_that_ends_at_a_joint_ends_the_stream(rsx, eng):
+    # Go's flate.Writer.Close() ends a stream with an empty stored FINAL block, 01 00 00 FF FF, which holds the
+    # marker the cut search looks for.  Bytes behind it that happen to decode (a second stream) are not part of
+    # the item: the reference stops at the final block (src/decompress/mod.rs:246-249) and so must a stream that
+    # is cut into parts there.
+    rng = np.random.default_rng(17)
+    noise = bytearray(rng.integers(0, 256, 1200000, dtype=np.uint8).tobytes())
+    at = noise.find(b"\x00\x00\xff\xff")
+    while at >= 0:   # (the only markers in the item are the ones placed below)
+        noise[at] = 1
+        at = noise.find(b"\x00\x00\xff\xff")
+    noise = bytes(noise)
+
+    def stored(b, final=0):
+        return bytes([final]) + len(b).to_bytes(2, "little") + (len(b) ^ 0xFFFF).to_bytes(2, "little") + b
+
+    head = noise[:1100000]
+    a = b"".join(stored(head[k:k + 65535]) for k in range(0, len(head), 65535))
+    a += stored(b"")                       # a full flush
+    a += stored(noise[1100000:1140000])    # more than a search tile of stored bytes behind it ...
+    a += stored(b"", 1)                    # ... so that this marker is the first of its tile
+    a_data = noise[:1140000]
+    text = corpus.text(300000, 77)
+    b = zlib.compress(text, 6)[2:-4]
+    check_against_oracle(eng, [a + b, a], [len(a_data) + len(text) + 100, len(a_data)], rsx.FORMAT_DEFLATE)
+    got, status = eng.batch_decompress([a + b], [len(a_data) + len(text) + 100], rsx.FORMAT_DEFLATE)
+    assert list(status) == [0] and got[0] == a_data
+    assert eng.last_parts() >= 2
+    # with a trailer behind the final block the trailer is found where the stream ends
+    z = b"\x78\x9c" + a + zlib.adler32(a_data).to_bytes(4, "big")
+    check_against_oracle(eng, [z, z + b], [len(a_data), len(a_data) + 7], rsx.FORMAT_ZLIB)
+
+
 def test_parts_are_off_for_short_streams(rsx, eng):
     # (streams that average less than 256 KiB of input are not searched for joints)
     data = [corpus.text(300000, 40 + i) for i in range(4)]
