@@ -20,9 +20,10 @@
  *     may write     out[out_off[i] .. out_off[i+1])         (n+1 offsets).
  *     Nothing outside slot i is written for item i.
  *   - The library never allocates memory the caller can see.
- *   - An engine is bound to one GPU.  Calls on one engine serialise on an
- *     internal mutex; use one engine per thread (or per process/GPU) for
- *     concurrency.
+ *   - An engine is bound to one GPU (rsx_engine_create) or to several
+ *     (rsx_engine_create_multi: the host entry points then cut every batch into
+ *     one contiguous range of items per GPU).  Calls on one engine serialise on
+ *     an internal mutex per GPU; use one engine per thread for concurrency.
  */
 #ifndef RSX_DEFLATE_H
 #define RSX_DEFLATE_H
@@ -75,7 +76,33 @@ typedef struct rsx_engine rsx_engine;
  * launch on, or NULL to let the engine create its own.
  */
 int rsx_engine_create(int device, void *stream, rsx_engine **out);
+/* GPUs this process can see (0 when there is none or the runtime fails) */
+int rsx_device_count(void);
+/*
+ * An engine over `ndev` GPUs (devices[r] may repeat: every entry gets an engine,
+ * stream and workspace of its own).  Buffers of a batch are independent
+ * (src/batch.rs:34-57, :79-100), so the host entry points (rsx_batch_compress,
+ * rsx_batch_compress_flush, rsx_batch_decompress, rsx_batch_decompress_members,
+ * rsx_batch_checksum) cut a batch into ndev contiguous ranges of items balanced
+ * by input bytes, run every range on its GPU from a host thread of its own and
+ * write sizes, status and payload straight into the caller's arrays: results
+ * are those of a single-GPU engine, item by item.  Where CudaBatchCompressor::new
+ * opens device 0 (src/batch_cuda.rs:23) a binding passes the visible devices.
+ * The *_device entry points take pointers into one GPU's memory and refuse such
+ * an engine (RSX_E_INVALID); ndev == 1 gives an ordinary engine.
+ */
+int rsx_engine_create_multi(const int *devices, int ndev, rsx_engine **out);
+/* number of GPU engines behind this handle (1 for rsx_engine_create) */
+int rsx_engine_num_devices(const rsx_engine *e);
 void rsx_engine_destroy(rsx_engine *e);
+/*
+ * Engine options.  RSX_OPT_VERIFY_FHCRC (default 0): a gzip member whose header
+ * carries a header CRC (FLG.FHCRC, RFC 1952 2.3.1) has it checked and is
+ * RSX_BAD_DATA when it does not match; the reference skips the field unread
+ * (src/decompress/mod.rs:1186-1188), which stays the default.
+ */
+#define RSX_OPT_VERIFY_FHCRC 1
+int rsx_engine_set_option(rsx_engine *e, int option, int value);
 /* last HIP / argument error text of this engine (valid until the next call) */
 const char *rsx_engine_last_error(const rsx_engine *e);
 /* the hipStream_t all work of this engine is launched on */
@@ -154,8 +181,12 @@ int rsx_batch_decompress(rsx_engine *e, int format, const uint8_t *in, const uin
  * item's slot; out_sizes[i] = bytes of all members together.  Zero bytes behind
  * the last member are padding; anything else that is not a member makes the
  * item RSX_BAD_DATA; a member that fails gives the item that member's status.
- * Each member's CRC-32 and ISIZE are verified.
+ * Each member's CRC-32 and ISIZE are verified.  Every member depth costs one
+ * chain of launches: an item with more than RSX_MAX_GZIP_MEMBERS members is
+ * RSX_BAD_DATA.  An engine error in the middle (negative return) leaves the
+ * items still in flight with RSX_INTERNAL_ERROR and out_sizes 0.
  */
+#define RSX_MAX_GZIP_MEMBERS 4096
 int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_t *in_off, size_t n,
                                  uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
                                  int32_t *status);
@@ -209,6 +240,8 @@ int rsx_batch_checksum_device(rsx_engine *e, int kind, uint32_t init, const uint
  * beyond them the call returns RSX_E_INVALID and does nothing.  All engines on
  * one GPU share that GPU's array: two such calls that overlap in time on one
  * GPU (different engines or streams) race; calls on one stream are safe.
+ * rsx_engine_last_kernel_ms is not meaningful for a call that was captured
+ * into a graph (its events are recorded when the graph runs, if at all).
  */
 #define RSX_NOALLOC_MAX_ITEMS 8192
 #define RSX_NOALLOC_MAX_TOTAL_OUT (1ull << 30)

@@ -8,10 +8,19 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/rsx_deflate.h"
 
+struct HostPipe;   // api.cpp: streams, pinned buffers and copy threads of the host entry points
+
 struct rsx_engine {
+    // An engine made by rsx_engine_create_multi for more than one device owns one engine per device and no GPU
+    // state of its own: its host entry points cut a batch into one contiguous range of items per device.
+    std::vector<rsx_engine *> subs;
+    HostPipe *pipe = nullptr;   // created by the first host entry point call
+    bool verify_fhcrc = false;  // RSX_OPT_VERIFY_FHCRC
+
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -41,6 +50,9 @@ struct rsx_engine {
 
     const uint32_t *d_last_fallbacks = nullptr;   // device word: streams of the last decompress call the one-kernel decoder took
     const uint32_t *d_last_parts = nullptr;   // device word: parts of the last decompress call (in the workspace)
+    // The host entry points run a batch slice by slice: they add every slice's words up here (device memory,
+    // 4 words: parts, streams taken out behind the first / the second kernel, streams decoded twice)
+    uint32_t *d_diag = nullptr;
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
@@ -91,6 +103,10 @@ int checksum_launch(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
                     uint64_t max_item, uint32_t *values, bool trusted_max);
 
 // inflate.hip
+// The `format` of inflate_launch may carry this flag: a gzip header's FHCRC field is checked (RFC 1952 2.3.1;
+// the reference skips the field, src/decompress/mod.rs:1186-1188) and a mismatch is RSX_BAD_DATA.
+constexpr int kFormatMask = 0xFF;
+constexpr int kFormatVerifyFhcrc = 0x100;
 // looks up this GPU's copy of the static scratch array (call with the engine's device current)
 int inflate_static_scratch(rsx_engine *e);
 // split: the two-kernel decoder (tokens in the workspace) with the one-kernel decoder for what it leaves;

@@ -1418,9 +1418,13 @@ struct ContainerInfo {
     int status;        // -1 = ok so far
 };
 
-// zlib / gzip header checks, src/decompress/mod.rs:1079-1095 and :1149-1192
+// zlib / gzip header checks, src/decompress/mod.rs:1079-1095 and :1149-1192.  With kFormatVerifyFhcrc in
+// `format` the header CRC of a gzip member that has one (FLG.FHCRC) is checked as well: the low 16 bits of the
+// CRC-32 of the header bytes in front of it (RFC 1952 2.3.1); the reference skips the field (:1186-1188).
 __device__ ContainerInfo parse_container(int format, const uint8_t *in, uint64_t in_len)
 {
+    const bool verify_fhcrc = (format & kFormatVerifyFhcrc) != 0;
+    format &= kFormatMask;
     ContainerInfo ci{0, 0, -1};
     if (format == RSX_FORMAT_ZLIB) {
         if (in_len < 6) {
@@ -1462,6 +1466,17 @@ __device__ ContainerInfo parse_container(int format, const uint8_t *in, uint64_t
         if (h + 8 > in_len) {
             ci.status = RSX_SHORT_INPUT;
             return ci;
+        }
+        if (verify_fhcrc && (flg & 0x02)) {
+            uint32_t crc = ~0u;   // (headers are tens of bytes: bit by bit, no table)
+            for (uint64_t k = 0; k + 2 < h; k++) {
+                crc ^= in[k];
+                for (int b = 0; b < 8; b++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1)));
+            }
+            if (((~crc) & 0xFFFF) != ((uint32_t)in[h - 2] | ((uint32_t)in[h - 1] << 8))) {
+                ci.status = RSX_BAD_DATA;
+                return ci;
+            }
         }
         ci.hdr = (uint32_t)h;
         ci.trailer = 8;
@@ -2762,6 +2777,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                    const InflateSlices *slices)
 {
     if (n == 0) return RSX_OK;
+    const int fmt = format & kFormatMask;   // (`format` itself goes to the kernels that judge the container header)
     const uint64_t *in_hi = slices ? slices->in_hi : in_off + 1;
     const uint64_t *out_hi = slices ? slices->out_hi : out_off + 1;
     const uint64_t *in_base_p = slices ? slices->in_base : in_off;
@@ -2859,7 +2875,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
     } else if (split) {
         inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
                                                           in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
-        inflate_expand_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, out, out_off, out_sizes, status,
+        inflate_expand_kernel<false><<<grid, kT, 0, e->stream>>>(fmt, in, in_off, grid, out, out_off, out_sizes, status,
                                                                  lay, in_hi, out_hi, in_base_p, nullptr, ExpandChain{});
         // whatever the two left (damaged streams, slots that are too small, streams that need more
         // token space than the workspace has) is decoded again by the one-kernel decoder
@@ -2908,15 +2924,15 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
 #endif
     e->timed = true;
     RSX_HIP(e, hipGetLastError());
-    if (format != RSX_FORMAT_DEFLATE) {
-        int kind = format == RSX_FORMAT_GZIP ? RSX_CHECKSUM_CRC32 : RSX_CHECKSUM_ADLER32;
-        uint32_t init = format == RSX_FORMAT_GZIP ? 0u : 1u;
+    if (fmt != RSX_FORMAT_DEFLATE) {
+        int kind = fmt == RSX_FORMAT_GZIP ? RSX_CHECKSUM_CRC32 : RSX_CHECKSUM_ADLER32;
+        uint32_t init = fmt == RSX_FORMAT_GZIP ? 0u : 1u;
         // failed items have out_sizes 0 and cost nothing; the slot sizes are the caller's word, so the
         // segment grid is derived from the produced sizes on the device (trusted_max = false)
         int r = checksum_launch(e, kind, init, out, out_off, out_sizes, n, total_out, max_out, sums, false);
         if (r != RSX_OK) return r;
         verify_trailer_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, e->stream>>>(
-            format, in, in_off, (uint32_t)n, body_end, sums, out_sizes, status, in_used);
+            fmt, in, in_off, (uint32_t)n, body_end, sums, out_sizes, status, in_used);
         RSX_HIP(e, hipGetLastError());
     }
     return RSX_OK;

@@ -19,7 +19,11 @@ _LOCK = threading.Lock()
 _P = C.c_void_p
 SYMBOLS = [
     ("rsx_engine_create", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    ("rsx_device_count", C.c_int, []),
+    ("rsx_engine_create_multi", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    ("rsx_engine_num_devices", C.c_int, [_P]),
     ("rsx_engine_destroy", None, [_P]),
+    ("rsx_engine_set_option", C.c_int, [_P, C.c_int, C.c_int]),
     ("rsx_engine_last_error", C.c_char_p, [_P]),
     ("rsx_engine_stream", _P, [_P]),
     ("rsx_engine_synchronize", C.c_int, [_P]),
@@ -44,6 +48,8 @@ SYMBOLS = [
     ("rsx_batch_decompress_device_noalloc", C.c_int,
      [_P, C.c_int, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
 ]
+OPT_VERIFY_FHCRC = 1
+MAX_GZIP_MEMBERS = 4096
 NOALLOC_MAX_ITEMS = 8192
 NOALLOC_MAX_TOTAL_OUT = 1 << 30
 
@@ -79,6 +85,11 @@ def compress_bound(fmt, n):
     return load_library().rsx_compress_bound(fmt, n)
 
 
+def device_count():
+    """GPUs the library can see (rsx_device_count)."""
+    return int(load_library().rsx_device_count())
+
+
 def _np_ptr(a):
     return a.ctypes.data if a.size else None
 
@@ -86,14 +97,29 @@ def _np_ptr(a):
 class Engine:
     """One engine = one GPU (rsx_engine).  `stream` is a raw hipStream_t or None."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, devices=None):
+        """`devices`: a list of GPU ordinals for an engine over several GPUs (rsx_engine_create_multi);
+        otherwise one engine on `device`."""
         self._lib = load_library()
         h = _P()
-        r = self._lib.rsx_engine_create(device, stream, C.byref(h))
-        if r != 0:
-            raise RsxError("rsx_engine_create(device=%d) failed with %d (no usable GPU?)" % (device, r))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            r = self._lib.rsx_engine_create_multi(arr, len(devices), C.byref(h))
+            if r != 0:
+                raise RsxError("rsx_engine_create_multi(%r) failed with %d (no usable GPU?)" % (list(devices), r))
+        else:
+            r = self._lib.rsx_engine_create(device, stream, C.byref(h))
+            if r != 0:
+                raise RsxError("rsx_engine_create(device=%d) failed with %d (no usable GPU?)" % (device, r))
         self._h = h
         self.device = device
+
+    @property
+    def num_devices(self):
+        return int(self._lib.rsx_engine_num_devices(self._h))
+
+    def set_option(self, option, value):
+        self._check(self._lib.rsx_engine_set_option(self._h, option, int(value)))
 
     def close(self):
         if getattr(self, "_h", None):
