@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: batch gzip decompress of 4096 x 1 MiB level-6 text
 buffers per GPU (BASELINE.json configs[1]), reported as GiB/s of bytes in + out,
-with the compress half of the metric (configs[2]: zlib level 6, 4096 x 1 MiB
-mixed text/binary) attached to the same JSON line as "secondary".
+with the other per-GPU shapes attached to the same JSON line as the "secondary"
+list: the compress half of the metric (configs[2]: zlib level 6, 4096 x 1 MiB
+mixed text/binary), one GPU's shard of configs[3] (8192 x 64 KiB gzip
+decompress) and of configs[4] (128 x 4 MiB JSON, raw DEFLATE level 12).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -45,16 +47,33 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 METRIC = "batch GiB/s in+out (compress@L6, decompress) at 1/2/4/8 GPUs; % HBM roofline"
 
 
+def kernel_sources_hash():
+    """sha256 (16 hex digits) over the engine's kernel sources: the measured HBM traffic in bench_traffic.json
+    belongs to the kernels it was collected from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libdeflate-rsx_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(key, which="dominant_kernels"):
     """HBM bytes per batch for the default workloads, taken from separate rocprofv3 --pmc passes
     (counters cannot be collected inside a timed run): of the kernel(s) the roofline entry names
     ("dominant_kernels") or of every kernel of the call, checksum and gather included
-    ("all_kernels"); None for any other configuration."""
+    ("all_kernels"); None for any other configuration, and None when the kernel sources have changed
+    since the counters were collected (the file records their hash)."""
     try:
         with open(os.path.join(ROOT, "bench_traffic.json")) as f:
-            e = json.load(f).get(key)
+            doc = json.load(f)
+        if doc.get("csrc_sha16") != kernel_sources_hash():
+            return None
+        e = doc.get(key)
         return e.get(which) if isinstance(e, dict) else None
-    except OSError:
+    except (OSError, ValueError):
         return None
 
 
@@ -100,7 +119,7 @@ def make_streams(distinct, buf_bytes, fmt, level, seed0, compressor="reference")
     return texts, streams
 
 
-def cpu_decompress_baseline(streams, buf_bytes, fmt, target_s=12.0):
+def cpu_decompress_baseline(streams, buf_bytes, fmt, target_s):
     """Times the CPU restatement of the reference decoder on the distinct streams
     (all host threads the box grants), repeated until ~target_s of work."""
     import oracle_lib as orc
@@ -231,6 +250,39 @@ def verify_rows(ctx, d_out, n, buf, texts, idx, d_status, d_sizes):
     return True
 
 
+def host_path_rate(ctx, streams, texts, buf, fmt, n=1024):
+    """What a compiled binding gets from rsx_batch_decompress with HOST pointers (the only thing
+    src/batch.rs hands over): copy in, kernels and copy out included.  Reported beside the headline,
+    never as `value`."""
+    eng = ctx.rsx.Engine(ctx.local_rank)
+    d = len(streams)
+    flat = np.concatenate([streams[i % d] for i in range(n)])
+    in_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(streams[i % d]) for i in range(n)], out=in_off[1:])
+    out_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(buf)
+    out = np.empty(n * buf, dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint64)
+    status = np.zeros(n, dtype=np.int32)
+
+    def call():
+        r = eng._lib.rsx_batch_decompress(eng._h, fmt, flat.ctypes.data, in_off.ctypes.data, n, out.ctypes.data,
+                                          out_off.ctypes.data, sizes.ctypes.data, status.ctypes.data)
+        assert r == 0 and (status == 0).all() and (sizes == buf).all()
+    call()   # (untimed: pages of `out` are touched, the workspace and the pinned buffers are allocated)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        call()
+    dt = (time.perf_counter() - t0) / reps
+    ok = all(out[i * buf:(i + 1) * buf].tobytes() == texts[i % d] for i in (0, 1, n // 2, n - 1))
+    eng.close()
+    if not ok:
+        raise SystemExit("bench.py: host-pointer decompress returned wrong bytes")
+    return {"gibps_in_plus_out": (flat.size + out.size) / dt / 2**30, "ms_per_call": dt * 1e3,
+            "what": "rsx_batch_decompress, %d x %d KiB gzip streams in pageable host memory, results back in host "
+                    "memory (PCIe both ways, slices overlapped)" % (n, buf // 1024)}
+
+
 def bench_decompress(args, ctx):
     """BASELINE.json configs[1]: batch gzip decompress, n x 1 MiB level-6 text per GPU (weak scaling)."""
     rsx = ctx.rsx
@@ -276,12 +328,14 @@ def bench_decompress(args, ctx):
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level)),
             "traffic_all_kernels": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level), "all_kernels"),
-            "kernel": "inflate_decode_kernel + inflate_expand_kernel (dependent launches, timed together with the marker search that cuts the streams into parts)",
+            "kernel": "inflate_decode_kernel + inflate_expand_kernel (dependent launches; kernel_ms spans the whole call: the marker search that cuts the streams into parts, both decoder kernels, the CRC-32 pass and the trailer check)",
             "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
         },
     }
     if ctx.world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_decompress_baseline(streams, buf, fmt)
+        res["cpu_baseline"] = cpu_decompress_baseline(streams, buf, fmt, args.cpu_seconds)
+    if ctx.world == 1 and args.host_path:
+        res["config"]["host_path"] = host_path_rate(ctx, streams, texts, buf, fmt)
     del d_in, d_out
     torch.cuda.empty_cache()
     return res
@@ -350,7 +404,7 @@ def bench_compress(args, ctx):
                      "traffic": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level)),
                      "traffic_all_kernels": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level),
                                                              "all_kernels"),
-                     "kernel": "deflate_chunks_kernel (+ deflate_emit_kernel in kernel_ms)", "kernel_ms": k_ms,
+                     "kernel": "deflate_chunks_kernel (dominant; kernel_ms spans the whole call: match, emit, checksum, plan, place)", "kernel_ms": k_ms,
                      "algorithmic_bytes": total_in + total_out},
     }
     if ctx.world == 1 and not args.no_cpu_baseline:
@@ -363,7 +417,7 @@ def bench_compress(args, ctx):
             _, _, csz, cst = orc.batch_compress(flat, off, ofmt, level, threads=th)
             reps += 1
             cdt = time.perf_counter() - t1
-            if cdt >= 12.0:
+            if cdt >= args.cpu_seconds:
                 break
         res["cpu_baseline"] = {"value": reps * (distinct * buf + int(csz.sum())) / cdt / 2**30,
                                "unit": "GiB/s", "cores": th, "kind": "port",
@@ -436,7 +490,7 @@ def bench_strong(args, ctx):
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "inflate_decode_kernel + inflate_expand_kernel (dependent launches, timed together with the marker search that cuts the streams into parts)",
+            "kernel": "inflate_decode_kernel + inflate_expand_kernel (dependent launches; kernel_ms spans the whole call: the marker search that cuts the streams into parts, both decoder kernels, the CRC-32 pass and the trailer check)",
             "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
         },
     }
@@ -521,7 +575,10 @@ def main():
     ap.add_argument("--buf-kib", type=int, default=None, help="uncompressed KiB per stream (1024; strong: 64)")
     ap.add_argument("--distinct", type=int, default=64, help="distinct buffers generated on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the compress leg of the default run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other legs of the default run")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work per cpu_baseline sample")
+    ap.add_argument("--host-path", action="store_true", default=None,
+                    help="also time rsx_batch_decompress through host pointers (default: with the secondary legs)")
     ap.add_argument("--level", type=int, default=6, help="compress only")
     ap.add_argument("--corpus", choices=["mixed", "json", "text"], default="mixed",
                     help="compress only: mixed = zlib (headline), json/text = raw deflate")
@@ -542,6 +599,8 @@ def main():
     if args.buf_kib is None:
         args.buf_kib = 64 if strong else 1024
 
+    if args.host_path is None:
+        args.host_path = not args.no_secondary and args.op == "decompress" and not strong
     ctx = Ctx(args)
     if strong:
         res = bench_strong(args, ctx)
@@ -552,12 +611,27 @@ def main():
     else:
         res = bench_decompress(args, ctx)
         if not args.no_secondary:
-            sec = bench_compress(args, ctx)
-            res["secondary"] = {"metric": METRIC, "value": sec["value"], "unit": sec["unit"],
-                                "ms_per_step": sec["ms_per_step"], "config": sec["config"],
-                                "roofline": sec["roofline"]}
-            if "cpu_baseline" in sec:
-                res["secondary"]["cpu_baseline"] = sec["cpu_baseline"]
+            # the other per-GPU shapes of BASELINE.json: configs[2] (the compress half of the metric), one GPU's
+            # shard of configs[3] (65536 x 64 KiB gzip over 8 GPUs) and of configs[4] (1024 x 4 MiB JSON, raw level 12)
+            def leg(**over):
+                a = argparse.Namespace(**vars(args))
+                a.host_path = False
+                a.cpu_seconds = min(args.cpu_seconds, 8.0)
+                for k, v in over.items():
+                    setattr(a, k, v)
+                return a
+            legs = [(bench_compress, leg(corpus="mixed", level=6)),
+                    (bench_decompress, leg(streams=8192, buf_kib=64, steps=min(args.steps, 5))),
+                    (bench_compress, leg(streams=128, buf_kib=4096, corpus="json", level=12, distinct=16,
+                                         steps=min(args.steps, 2), warmup=1))]
+            res["secondary"] = []
+            for fn, a in legs:
+                sec = fn(a, ctx)
+                entry = {"metric": METRIC, "value": sec["value"], "unit": sec["unit"], "steps": a.steps, "warmup": a.warmup,
+                         "ms_per_step": sec["ms_per_step"], "config": sec["config"], "roofline": sec["roofline"]}
+                if "cpu_baseline" in sec:
+                    entry["cpu_baseline"] = sec["cpu_baseline"]
+                res["secondary"].append(entry)
     if ctx.rank == 0:
         line = {"metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": ctx.world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],

@@ -110,9 +110,9 @@ void *rsx_engine_stream(const rsx_engine *e);
 /* blocks until everything queued by *_device calls has finished */
 int rsx_engine_synchronize(rsx_engine *e);
 /*
- * Duration in milliseconds of the dominant kernel of the most recent
- * *_device call (inflate, deflate or checksum kernel), measured with HIP
- * events on the engine's stream.  Synchronises.  Negative if none was run.
+ * Duration in milliseconds of the kernels of the most recent *_device call
+ * (all of them, first launch to last), measured with HIP events on the
+ * engine's stream.  Synchronises.  Negative if none was run.
  */
 float rsx_engine_last_kernel_ms(rsx_engine *e);
 /*
