@@ -192,6 +192,34 @@ int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_
                                  int32_t *status);
 
 /*
+ * One step of an incremental raw-DEFLATE decoder: the engine's counterpart of
+ * Decompressor::decompress_streaming (src/decompress/mod.rs:213-353), which
+ * DeflateDecoder<R> drives through a sliding window (src/stream.rs:235-377).
+ * The stream goes on at bit `in_bit` (0..7) of in[0]; `history` holds the last
+ * bytes produced so far (up to 32768 of them are used: what a match can reach
+ * back), new bytes go to out[0 .. out_cap).  The reference's state machine can
+ * stop anywhere; this one stops BETWEEN TWO BLOCKS: it decodes every whole
+ * block that `in` holds and `out` has room for and reports
+ *   *in_next_bit   the first unread bit, counted from bit 0 of in[0] (the next
+ *                  step starts at byte in_next_bit / 8, bit in_next_bit % 8),
+ *   *out_produced  the bytes written to `out`,
+ *   *status        RSX_SUCCESS: the final block has ended (in_next_bit = the
+ *                  end of the stream); RSX_SHORT_INPUT: the next block is not
+ *                  whole in `in` (more input; a step that consumed nothing
+ *                  needs a longer `in`, and at the end of the input the stream
+ *                  is truncated); RSX_INSUFFICIENT_SPACE: the next block does
+ *                  not fit (call again with room; a step that produced nothing
+ *                  needs a larger `out`); RSX_BAD_DATA: the next block is
+ *                  damaged (the blocks in front of it have been delivered).
+ * Host pointers, synchronous; one stream is the work of one workgroup, so this
+ * is the bounded-memory path, not the fast one (rsx_batch_decompress decodes a
+ * whole stream, cut at its chunk joints, on all of the GPU).
+ */
+int rsx_inflate_stream_step(rsx_engine *e, const uint8_t *in, size_t in_len, uint32_t in_bit,
+                            const uint8_t *history, size_t history_len, uint8_t *out, size_t out_cap,
+                            uint64_t *in_next_bit, size_t *out_produced, int32_t *status);
+
+/*
  * crc32 / adler32 (src/crc32/mod.rs:332, src/adler32/mod.rs:115) over every
  * item of a batch: values[i] = f(init, item i), init = 0 for CRC-32 and 1 for
  * Adler-32 when starting a new checksum.  Host pointers.

@@ -1194,6 +1194,58 @@ int rsx_batch_decompress_members(rsx_engine *e, const uint8_t *in, const uint64_
     });
 }
 
+int rsx_inflate_stream_step(rsx_engine *e, const uint8_t *in, size_t in_len, uint32_t in_bit,
+                            const uint8_t *history, size_t history_len, uint8_t *out, size_t out_cap,
+                            uint64_t *in_next_bit, size_t *out_produced, int32_t *status)
+{
+    if (!e) return RSX_E_INVALID;
+    if (!e->subs.empty()) e = e->subs[0];   // (one stream is one workgroup's work: the first GPU)
+    if (!in_next_bit || !out_produced || !status || (!in && in_len) || (!history && history_len) || (!out && out_cap))
+        return bad(e, "null pointer");
+    if (in_bit > 7) return bad(e, "in_bit must be 0..7");
+    if (history_len > 32768) {   // a match reaches back 32 KiB at most
+        history += history_len - 32768;
+        history_len = 32768;
+    }
+    if ((uint64_t)out_cap + history_len >= (1ull << 32) - (1ull << 16) || (uint64_t)in_len >= (1ull << 32))
+        return bad(e, "step too large (input and output room must be < 4 GiB)");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    const uint64_t slot = (uint64_t)history_len + out_cap;
+    int r = ws_reserve(e, align_up(in_len + 64, 256) + align_up(slot + 64, 256) + 1024);
+    if (r != RSX_OK) return r;
+    uint8_t *d_in = static_cast<uint8_t *>(ws_take(e, in_len + 64));
+    uint8_t *d_out = static_cast<uint8_t *>(ws_take(e, slot + 64));
+    uint64_t *ctl = static_cast<uint64_t *>(ws_take(e, 10 * sizeof(uint64_t)));
+    if (!d_in || !d_out || !ctl) {
+        e->err = "workspace carve failed";
+        return RSX_E_NOMEM;
+    }
+    uint64_t h[10] = {0, in_len, 0, slot, history_len, 0, 0, 0, in_bit, 0};
+    if (in_len) RSX_HIP(e, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, e->stream));
+    if (history_len) RSX_HIP(e, hipMemcpyAsync(d_out, history, history_len, hipMemcpyHostToDevice, e->stream));
+    RSX_HIP(e, hipMemcpyAsync(ctl, h, sizeof h, hipMemcpyHostToDevice, e->stream));
+    RSX_HIP(e, hipStreamSynchronize(e->stream));   // (h lives on this stack)
+    r = inflate_resume_launch(e, d_in, in_len, d_out, ctl);
+    if (r != RSX_OK) return r;
+    RSX_HIP(e, hipMemcpyAsync(h, ctl, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    RSX_HIP(e, hipStreamSynchronize(e->stream));
+    const uint64_t produced = h[6], next_bit = h[5];
+    const int32_t st = (int32_t)(uint32_t)h[9];
+    if (produced > out_cap || next_bit > (uint64_t)in_len * 8) {
+        e->err = "device returned a position outside the step's buffers";
+        return RSX_E_DEVICE;
+    }
+    if (produced) {
+        RSX_HIP(e, hipMemcpyAsync(out, d_out + history_len, produced, hipMemcpyDeviceToHost, e->stream));
+        RSX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    *in_next_bit = st == RSX_INTERNAL_ERROR ? in_bit : next_bit;
+    *out_produced = (size_t)produced;
+    *status = st;
+    return RSX_OK;
+}
+
 int rsx_batch_checksum(rsx_engine *e, int kind, uint32_t init, const uint8_t *in,
                        const uint64_t *in_off, size_t n, uint32_t *values)
 {

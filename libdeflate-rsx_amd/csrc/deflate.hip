@@ -1294,7 +1294,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
         }
         // the last lane also covers slot kCT when the chunk ends inside this batch
         // (nslots = kCT + 1 only when tail and n - b0 == kCT): handled below by lane kCT-1
-        uint32_t x_next = kEnd, x_ntoks = 0, x_t0 = 0;
+        uint32_t x_next = kEnd, x_t0 = 0;
         if (tid == kCT - 1 && lim == kCT + 1) {
             const uint32_t s = kCT;
             uint32_t len = L.m_len[s], pos = base_pos + s;
@@ -1305,7 +1305,6 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
                 x_t0 = byte_at(pos);
                 x_next = s + 1;
             }
-            x_ntoks = 1;
         }
         // Which slots start a token: the chain entry -> next(entry) -> ... over slots 0..kCT (slot kCT+1 =
         // beyond).  Every wave first squares the pointers of its own 64 slots through lane exchanges, six times,

@@ -127,6 +127,9 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                    const uint64_t *out_off, uint64_t *out_sizes, int32_t *status, bool split,
                    const InflateSlices *slices = nullptr);
 
+// one resumable item through the one-kernel decoder; ctl: ten u64 of device memory, see inflate.hip
+int inflate_resume_launch(rsx_engine *e, const uint8_t *d_in, uint64_t in_len, uint8_t *d_out, uint64_t *ctl);
+
 // deflate.hip
 size_t deflate_ws_bytes(size_t n, uint64_t total_in, uint64_t max_item, int level);
 int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, const uint64_t *in_off,

@@ -6,32 +6,28 @@
 // build (:1324-1495), Huffman block body + LZ copy (:509-1072), zlib / gzip
 // framing (:1074-1240).  Result codes are the reference's DecompressResult.
 //
-// One 256-thread workgroup decodes one stream in rounds (31 KB of LDS, so that five
-// workgroups share a CU):
-//   1. stage   a 4 KiB window of compressed bytes into LDS, one 16-byte coalesced
-//              load per lane;
-//   2. decode  all 256 lanes decode Huffman symbols at once.  The window is cut
-//              into 126-bit sub-sequences, lane i starts at a guessed bit position
-//              inside sub-sequence i (the end of a warm-up decode over the 720 bits in
-//              front of it) and decodes until it crosses into sub-sequence i+1.  Huffman
-//              streams re-synchronise, so after a few passes of "restart where the
-//              previous lane really ended" every lane's start is the true one
-//              (lane 0 always is).  A prefix sum of the bytes each lane produces
-//              gives its output position, then each lane decodes once more and
-//              emits: literals straight into a 16 KiB LDS ring that mirrors the
-//              tail of the output, matches as a queue of start positions with
-//              distance and length parked in the ring bytes the match will fill;
-//   3. copy    all lanes resolve the queued matches in parallel, 2048 output
-//              bytes at a time, by pointer jumping over per-byte source pointers;
-//              sources older than the ring are read back from the already
-//              written output;
-//   4. flush   the round's bytes leave the ring as 16-byte coalesced stores.
-// Block headers are read by one lane; the decode tables are built by the first wave.
-// HBM traffic is therefore one read of the compressed bytes and one write of
-// the output; the history window is served from LDS (and L2 for far matches).
+// A batch is decoded by two kernels, one 256-thread workgroup per stream (or per part of a stream) in each:
+//   inflate_decode_kernel  Huffman decoding only.  Rounds over a 15 KiB LDS window of the compressed bytes;
+//              the window is cut into 256 sub-sequences of up to 480 bits, every lane starts at a guessed
+//              token boundary (the end of a 1024-bit warm-up decode in front of its sub-sequence) and decodes
+//              until it crosses into the next one; passes of "restart where the lane in front really ended"
+//              converge because Huffman streams re-synchronise.  Tokens (a literal, or length and distance)
+//              go to token rows in device memory, [row k][lane]: the k-th token of every sub-sequence.  Block
+//              headers are read and the decode tables built by the first wave, all 64 lanes taking part.
+//   inflate_expand_kernel  LZ77 expansion only.  Groups of sub-sequences that fit a 16 KiB LDS ring are walked
+//              from their checkpoints in parallel (literals into the ring, matches into a queue), then resolved
+//              2048 output bytes at a time by pointer jumping over per-byte source pointers (overlapping and
+//              chained matches resolve in log steps), and leave the ring as 16-byte coalesced stores.
+// Few, large streams are first cut at the sync-flush joints the reference's chunked compressor writes
+// (part_* kernels) so that every 256 KiB chunk is a workgroup's worth of work of its own.
+// inflate_kernel is the older one-kernel decoder (stage / decode / copy / flush rounds in one workgroup, 31 KB of
+// LDS): it takes whatever the two kernels give up -- damaged streams, slots that are too small, streams that run
+// out of token rows -- decodes it again from the start and reports the reference's status code, and it serves
+// rsx_batch_decompress_device_noalloc, whose static scratch holds no token rows.
+// zlib / gzip: a CRC-32 / Adler-32 pass over the produced bytes (checksum.hip) and verify_trailer_kernel.
 //
-// Roofline: HBM by design (algorithmic bytes per stream = compressed_len +
-// uncompressed_len); in practice the kernel is bound by vector-ALU issue.
+// Roofline: HBM by design (algorithmic bytes per stream = compressed_len + uncompressed_len); the token rows
+// cost 4 bytes per token written and read, and both kernels are bound by vector-ALU issue, not by memory.
 #include "engine.h"
 
 #include <cstdlib>
@@ -816,6 +812,7 @@ template <class LS>
 __device__ __noinline__ void header_step(LS &L, const uint8_t *body, uint64_t body_len, int64_t win_bit0)
 {
     unsigned long long th0 = SPLIT_T_NOW();
+    (void)th0;   // (read only by the phase timers of development builds)
     if (threadIdx.x == 0) parse_block_header(L, body, body_len, win_bit0);
     WAVE_SYNC();
     const uint32_t plan = L.hdr.plan;   // (uniform)
@@ -1254,6 +1251,7 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         const uint32_t sub_end = sub_start + kCopySub < round_end ? sub_start + kCopySub : round_end;
         unsigned long long tc = RSX_DEV_TIMERS == 2 ? clock64() : 0;
         unsigned long long ts = SPLIT_T_NOW();
+        (void)ts;   // (read only by the phase timers of development builds)
         // matches are sorted by destination: lane t looks at matches mcur + t, + kT, ...
         // The matches that end inside this step are a prefix of them (matches do not overlap);
         // every wave counts its own, the next step starts behind their sum.  The first lane of a
@@ -1484,6 +1482,20 @@ __device__ ContainerInfo parse_container(int format, const uint8_t *in, uint64_t
     return ci;
 }
 
+// Decoding that can be taken up again (rsx_inflate_stream_step, the engine's side of
+// Decompressor::decompress_streaming, src/decompress/mod.rs:213-353).  An item then starts at bit
+// start_bit[i] of its first byte, the first hist_len[i] bytes of its output slot are the output produced so far
+// (at most the 32 KiB a match can reach back), and the decoder reports the last place BETWEEN TWO BLOCKS it
+// reached: a stream whose input or output room ends inside a block is reported up to the end of the block
+// before (status RSX_SHORT_INPUT / RSX_INSUFFICIENT_SPACE, out_sizes = the bytes behind the history up to there,
+// end_bits = the item's bits up to there), so that the caller can go on from that bit with more input or room.
+// Damaged data reports the blocks in front of the damaged one the same way, with RSX_BAD_DATA.
+struct ResumeArgs {
+    const uint32_t *start_bit;   // null: items are whole streams (every other field is unused)
+    const uint64_t *hist_len;
+    uint64_t *end_bits;
+};
+
 // STATS builds add per-stream phase timers (development aid, RSX_INFLATE_STATS=1):
 // stats[item*8 + k]: 0 rounds, 1 speculation passes, 2 copy passes, 3..7 cycles in
 // stage / header / decode / copy / flush
@@ -1493,7 +1505,8 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     uint64_t total_in, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint64_t *__restrict__ body_end,
     unsigned long long *__restrict__ stats, int only_status, const uint64_t *__restrict__ in_hi,
-    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p, uint32_t *__restrict__ taken)
+    const uint64_t *__restrict__ out_hi, const uint64_t *__restrict__ in_base_p, uint32_t *__restrict__ taken,
+    ResumeArgs resume)
 {
     unsigned long long tS = 0, tH = 0, tD = 0, tC = 0, tF = 0, t0 = 0, nRounds = 0;
 #define STAT_BEGIN() do { if (STATS) t0 = clock64(); } while (0)
@@ -1530,8 +1543,15 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     c.body = in + ib + ci.hdr;
     c.body_len = (ie - ib) - ci.hdr - ci.trailer;
 
+    const bool resumable = resume.start_bit != nullptr;   // (uniform)
+    // history: output positions below `hist` were produced by earlier calls
+    uint32_t hist = 0;
+    if (resumable) {
+        const uint64_t h = resume.hist_len[item];
+        hist = (uint32_t)(h < c.out_cap ? h : c.out_cap);
+    }
     if (tid == 0) {
-        L.bitpos = 0;
+        L.bitpos = resumable ? (resume.start_bit[item] & 7u) : 0;
         L.status = -1;
         L.in_block = 0;
         L.final_block = 0;
@@ -1541,11 +1561,18 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
         L.stat_spec = 0;
         L.stat_copy = 0;
         L.stat_t[0] = L.stat_t[1] = L.stat_t[2] = L.stat_t[3] = 0;
-        L.round_start_lo = 0;
-        L.round_end_lo = 0;
+        L.round_start_lo = hist;
+        L.round_end_lo = hist;
         L.num_matches = 0;
     }
-    uint32_t flushed = 0;  // output positions below this are in global memory (uniform)
+    // the ring mirrors the newest output bytes: what it would hold had this call produced the history
+    for (uint32_t k = tid; k < kRing && k < hist; k += kT) {
+        const uint32_t pos = hist - 1 - k;
+        L.ring[(pos + c.shift) & kRingMask] = c.out[pos];
+    }
+    uint32_t flushed = hist;  // output positions below this are in global memory (uniform)
+    uint64_t ck_bit = resumable ? (resume.start_bit[item] & 7u) : 0;   // the last place between two blocks (uniform)
+    uint32_t ck_out = hist;
     uint64_t seen_bitpos = ~0ull;  // progress watchdog (uniform)
     int stalled = 0;
     WG_SYNC();
@@ -1555,6 +1582,10 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
         // and must not spin on the GPU
         {
             const uint64_t bp = L.bitpos;
+            if (!L.in_block && L.stored_len < 0) {   // (uniform) between two blocks
+                ck_bit = bp;
+                ck_out = L.round_end_lo;
+            }
             stalled = bp == seen_bitpos ? stalled + 1 : 0;
             seen_bitpos = bp;
             WG_SYNC();
@@ -1663,9 +1694,19 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
     const int st = L.status;
     const uint32_t produced = L.round_end_lo;
     if (st == RSX_SUCCESS) flush_range(L, c, flushed, produced);
+    if (resumable && st != RSX_SUCCESS && st != RSX_INTERNAL_ERROR) {
+        // up to the end of the last whole block: what is left of it in the ring (the tail of the round that
+        // ended it: rounds behind it wrote past it, and a failing round copies nothing)
+        if (ck_out > flushed) flush_range(L, c, flushed, ck_out);
+    }
     if (tid == 0) {
         status[item] = st;
         out_sizes[item] = st == RSX_SUCCESS ? produced : 0;
+        if (resumable) {
+            const bool partial = st != RSX_SUCCESS && st != RSX_INTERNAL_ERROR;
+            out_sizes[item] = st == RSX_SUCCESS ? produced - hist : partial ? ck_out - hist : 0;
+            resume.end_bits[item] = st == RSX_SUCCESS ? L.bitpos : partial ? ck_bit : 0;
+        }
         // first byte behind the DEFLATE stream, relative to the item start
         body_end[item] = ci.hdr + ((L.bitpos + 7) >> 3);
         if (STATS) {
@@ -1735,7 +1776,7 @@ enum { ROUND_END = 0, ROUND_TOKENS = 1, ROUND_STORED = 2 };
 struct RoundRec {
     uint32_t kind;      // ROUND_*
     uint32_t a;         // tokens: first row (the header row);   stored: length in bytes
-    uint32_t b;         // tokens: number of sub-sequences;       stored: low half of the source offset in the body
+    uint32_t b;         // tokens: number of sub-sequences | first column << 16;   stored: low half of the source offset in the body
     uint32_t c;         // tokens: 0, or 1 + the pool row its chunk starts at (a is then relative to the chunk);   stored: high half
 };
 
@@ -1760,8 +1801,10 @@ struct SplitLayout {
         return (rel * 8 >> kRowBitsLog2) + (uint64_t)item * (kTokCap + kHdrRows + 1);
     }
     __device__ uint64_t row_budget(uint64_t in_len) const { return (in_len * 8 >> kRowBitsLog2) + kTokCap + kHdrRows; }
-    __device__ uint64_t first_round(uint64_t rel, uint32_t item) const { return (rel >> 8) + (uint64_t)item * 66; }
-    __device__ uint64_t round_budget(uint64_t in_len) const { return (in_len >> 8) + 64; }
+    // (a round per block at least: zlib at memLevel 1 writes a block every 127 symbols, 27 bytes of input when
+    // the data is one repeated byte and the strategy Z_HUFFMAN_ONLY)
+    __device__ uint64_t first_round(uint64_t rel, uint32_t item) const { return (rel >> 4) + (uint64_t)item * 66; }
+    __device__ uint64_t round_budget(uint64_t in_len) const { return (in_len >> 4) + 64; }
 };
 static inline uint64_t split_tok_rows(size_t n, uint64_t total_in) { return (total_in * 8 >> kRowBitsLog2) + n * (kTokCap + kHdrRows + 1) + 2; }
 static inline uint64_t split_pool_rows(uint64_t total_in)
@@ -1769,7 +1812,7 @@ static inline uint64_t split_pool_rows(uint64_t total_in)
     const uint64_t r = (total_in * 8 >> kRowBitsLog2) / 4;   // a quarter on top of the streams' own rows
     return r < 1024 ? 1024 : r > 0x7FFFFF00ull ? 0x7FFFFF00ull : r;
 }
-static inline uint64_t split_round_recs(size_t n, uint64_t total_in) { return (total_in >> 8) + n * 66 + 2; }
+static inline uint64_t split_round_recs(size_t n, uint64_t total_in) { return (total_in >> 4) + n * 66 + 2; }
 
 typedef StreamLdsT<kDecWinBytes, 16> DecodeLds;
 typedef RSX_LDS DecodeLds LdsDecode;
@@ -1821,9 +1864,11 @@ __device__ inline TokScan scan_tokens(const LS &L, uint32_t start, uint32_t boun
 // L.bitpos on, sub-sequences of `sub_bits` bits, and leave the tokens in this round's rows.  Returns
 // (uniform) the number of rows the round used, header row included.  *sub_next receives the sub-sequence
 // length to use for the next round, *nlanes_ret the number of sub-sequences in the round.
+// `rows` points at the round's first column of its rows; the round has at most `max_lanes` sub-sequences (the
+// columns that are left of the rows when rounds share them).
 __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_t win_bit0, uint32_t sub_bits,
-                                        uint32_t *__restrict__ rows, uint32_t *nlanes_ret, uint32_t *sub_next,
-                                        uint32_t *bytes_ret)
+                                        uint32_t *__restrict__ rows, uint32_t max_lanes, uint32_t *nlanes_ret,
+                                        uint32_t *sub_next, uint32_t *bytes_ret)
 {
     constexpr uint32_t kWinLimitBits = DecodeLds::kWinLimitBits;
     const int tid = threadIdx.x;
@@ -1835,11 +1880,13 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
     uint32_t bound = lo + sub_bits;
     if (bound > kWinLimitBits) bound = kWinLimitBits;
     uint32_t n_active = (kWinLimitBits - b0 + sub_bits - 1) / sub_bits;
-    if (n_active > (uint32_t)kT) n_active = kT;
+    if (n_active > max_lanes) n_active = max_lanes;
+    if ((uint32_t)tid >= n_active) bound = lo;   // (a lane without a column decodes nothing)
     uint32_t *col = rows + tid;        // this lane's word of the first header row
 
     uint32_t guess = lo;
     unsigned long long tq = SPLIT_T_NOW();
+    (void)tq;   // (read only by the phase timers of development builds)
     if (tid > 0 && lo < bound) guess = warm_start(L, lo - b0 > kDecWarm ? lo - kDecWarm : b0, lo, end_b, litlen_bits);
     if (RSX_SPLIT_TIMERS && tid == 64) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(2, t - tq); tq = t; }
     uint32_t start = guess;
@@ -2005,6 +2052,11 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
     RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, item);
     const uint64_t own_budget = lay.row_budget(ie - ib), round_budget = lay.round_budget(ie - ib);
     uint64_t row = 0, nrounds = 0;   // (uniform) row: rows used of the stream's own, or of its current chunk of the pool
+    // Rounds share rows: a round ends where its block ends, and one that filled k of the 256 columns of its rows
+    // leaves the others to the rounds behind it, as long as enough of them are left.  Streams of short blocks
+    // (zlib with a small memLevel, a flush every few KB) would otherwise own rows that are mostly empty.
+    // row = first row of the open set of rows, set_rows = its height so far, col0 = its first free column.
+    uint32_t set_rows = 0, col0 = 0;
 
     if (tid == 0) {
         L.bitpos = 0;
@@ -2047,6 +2099,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         }
         int64_t win_bit0;
         unsigned long long ts = SPLIT_T_NOW();
+        (void)ts;   // (read only by the phase timers of development builds)
         stage_window(L, c, &win_bit0);
         WG_SYNC();
         if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(0, t - ts); ts = t; }
@@ -2096,10 +2149,13 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
                 chunk = at + 1;
                 row = 0;
                 row_budget = kPoolChunk;
+                set_rows = 0;   // (the open set stays behind in the rows the stream has left)
+                col0 = 0;
             }
-            uint32_t *const rows_at = (chunk ? lay.tok + (lay.pool_first + (chunk - 1)) * kT : tok) + row * kT;
+            uint32_t *const rows_at = (chunk ? lay.tok + (lay.pool_first + (chunk - 1)) * kT : tok) + row * kT + col0;
             uint32_t nlanes = 0, sub_next = sub_bits, round_bytes = 0;
-            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, rows_at, &nlanes, &sub_next, &round_bytes);
+            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, rows_at, (uint32_t)kT - col0, &nlanes,
+                                                      &sub_next, &round_bytes);
             // A sub-sequence near the round's front that ran into the token or byte limit ends the round there: the
             // round owns a full set of rows for a few sub-sequences' worth of input.  Where the stream has rows to
             // spare that is the cheaper way; where it has not (a short stream, the end of a share) the round is not
@@ -2114,9 +2170,18 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
             }
             produced += round_bytes;
             sub_bits = sub_next;
-            if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes, chunk};
-            row += used;
+            if (tid == 0) rounds[nrounds] = RoundRec{ROUND_TOKENS, (uint32_t)row, nlanes | (col0 << 16), chunk};
             nrounds++;
+            // the next round joins this one's rows when about as many columns are left as this one took
+            set_rows = max(set_rows, used);
+            const uint32_t left = (uint32_t)kT - (col0 + nlanes);
+            if (left >= 8 && left >= min(128u, nlanes + nlanes / 4)) {
+                col0 += nlanes;
+            } else {
+                row += set_rows;
+                set_rows = 0;
+                col0 = 0;
+            }
         }
         const int st = L.status;
         const int32_t stored = L.stored_len;
@@ -2277,6 +2342,7 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
     const RoundRec *const rounds = lay.rounds + lay.first_round(ib - in_base, seg);
     for (uint64_t r = 0; !bail; r++) {
         unsigned long long tb = SPLIT_T_NOW();
+        (void)tb;   // (read only by the phase timers of development builds)
         const RoundRec rec = rounds[r];
         if (rec.kind == ROUND_END) break;
         if (rec.kind == ROUND_STORED) {
@@ -2300,8 +2366,8 @@ __global__ __launch_bounds__(kT, RSX_XOCC) void inflate_expand_kernel(
             continue;
         }
         // a round of tokens: its sub-sequences go through the ring in groups that fit it
-        const uint32_t nlanes = rec.b;
-        const uint32_t *const rows = rec.c ? lay.tok + (lay.pool_first + (rec.c - 1) + rec.a) * kT : tok + (uint64_t)rec.a * kT;
+        const uint32_t nlanes = rec.b & 0xFFFF;   // (its columns start at rec.b >> 16: rounds share rows)
+        const uint32_t *const rows = (rec.c ? lay.tok + (lay.pool_first + (rec.c - 1) + rec.a) * kT : tok + (uint64_t)rec.a * kT) + (rec.b >> 16);
         const uint32_t info = (uint32_t)tid < nlanes ? rows[tid] : 0u;
         const uint32_t ntok = info & 0xFF, nm = (info >> 8) & 0xFF, bytes = info >> 16;
         uint32_t exb, exn;
@@ -2734,6 +2800,19 @@ int inflate_static_scratch(rsx_engine *e)
     return RSX_OK;
 }
 
+// One item decoded by the one-kernel decoder in its resumable mode (see ResumeArgs).  ctl = ten 64-bit words of
+// device memory: in_off[2], out_off[2] (the slot starts with the history), hist_len, end_bits, out_size,
+// body_end, start_bit (low half), status (low half); d_in / d_out are the bases the offsets refer to.
+int inflate_resume_launch(rsx_engine *e, const uint8_t *d_in, uint64_t in_len, uint8_t *d_out, uint64_t *ctl)
+{
+    const ResumeArgs ra{reinterpret_cast<const uint32_t *>(ctl + 8), ctl + 4, ctl + 5};
+    inflate_kernel<false><<<1, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, d_in, ctl, 1u, in_len, d_out, ctl + 2, ctl + 6,
+                                                    reinterpret_cast<int32_t *>(ctl + 9), ctl + 7, nullptr, 0, ctl + 1,
+                                                    ctl + 3, ctl, nullptr, ra);
+    RSX_HIP(e, hipGetLastError());
+    return RSX_OK;
+}
+
 static size_t inflate_common_ws_bytes(size_t n, uint64_t total_out)
 {
     return align_up(n * sizeof(uint64_t), 256) + align_up(n * sizeof(uint32_t), 256) +
@@ -2871,7 +2950,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                                                                 count, ExpandChain{parent_first, part_parent, out_off, status, out_sizes, grid, nullptr});
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
-                                                          in_base_p, taken);
+                                                          in_base_p, taken, ResumeArgs{});
     } else if (split) {
         inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
                                                           in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
@@ -2881,12 +2960,12 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         // token space than the workspace has) is decoded again by the one-kernel decoder
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
-                                                          in_base_p, taken);
+                                                          in_base_p, taken, ResumeArgs{});
     } else if (stats) {
         unsigned long long *d_stats = nullptr;   // (development aid: allocates and synchronises)
         RSX_HIP(e, hipMalloc(&d_stats, n * 12 * sizeof(unsigned long long)));
         inflate_kernel<true><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                         status, body_end, d_stats, 0, in_hi, out_hi, in_base_p, nullptr);
+                                                         status, body_end, d_stats, 0, in_hi, out_hi, in_base_p, nullptr, ResumeArgs{});
         (void)hipEventRecord(e->ev_end, e->stream);
         std::vector<unsigned long long> h(n * 12);
         RSX_HIP(e, hipMemcpy(h.data(), d_stats, h.size() * 8, hipMemcpyDeviceToHost));
@@ -2904,7 +2983,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                 (double)sum[11] / n);
     } else {
         inflate_kernel<false><<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, out, out_off, out_sizes,
-                                                          status, body_end, nullptr, 0, in_hi, out_hi, in_base_p, nullptr);
+                                                          status, body_end, nullptr, 0, in_hi, out_hi, in_base_p, nullptr, ResumeArgs{});
     }
 #if RSX_SPLIT_TIMERS
     if (split) {

@@ -36,6 +36,8 @@ SYMBOLS = [
     ("rsx_batch_compress_flush", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_decompress", C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("rsx_batch_decompress_members", C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    ("rsx_inflate_stream_step", C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P, C.c_size_t, _P, C.c_size_t,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]),
     ("rsx_batch_checksum", C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, C.c_size_t, _P]),
     ("rsx_crc32", C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("rsx_adler32", C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -235,6 +237,16 @@ class Engine:
         res = [out[int(out_off[i]):int(out_off[i]) + int(sizes[i])].tobytes() if status[i] == 0 else None
                for i in range(n)]
         return res, status[:n]
+
+    def inflate_stream_step(self, data, in_bit, history, out_cap):
+        """rsx_inflate_stream_step -> (status, next_bit, bytes produced)"""
+        data, history = bytes(data), bytes(history)
+        out = C.create_string_buffer(max(out_cap, 1))
+        nb, prod, st = C.c_uint64(0), C.c_size_t(0), C.c_int32(0)
+        self._check(self._lib.rsx_inflate_stream_step(self._h, C.c_char_p(data) if data else None, len(data), in_bit,
+                                                      C.c_char_p(history) if history else None, len(history),
+                                                      C.cast(out, _P), out_cap, C.byref(nb), C.byref(prod), C.byref(st)))
+        return st.value, nb.value, out.raw[:prod.value]
 
     def batch_checksum(self, items, kind, init=None):
         n = len(items)

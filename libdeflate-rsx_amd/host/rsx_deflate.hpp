@@ -451,14 +451,16 @@ class DeflateEncoder {
 
 // libdeflate::stream::DeflateDecoder<R> (src/stream.rs:235-377): reads one raw DEFLATE stream from a
 // reader and hands out the decompressed bytes through read().  Reader is anything callable as
-// size_t reader(uint8_t *dst, size_t cap) that returns 0 at the end of its data.  The reference feeds
-// a resumable CPU decoder through a 64 KiB window (src/decompress/mod.rs:213-353); the GPU decodes
-// whole streams, so the first read() pulls the reader dry and decodes everything at once (a large
-// stream is cut at its sync-flush joints and decoded part by part), growing the output until the
-// stream fits.  What read() returns afterwards is what the reference returns, byte for byte; an
-// error is reported by the first read() instead of after the bytes in front of it:
-// BadData -> InvalidData "deflate decompression failed" (:329-333), a stream that ends early ->
-// UnexpectedEof "unexpected EOF" (:359-370), an empty reader -> read() returns 0 (:371).
+// size_t reader(uint8_t *dst, size_t cap) that returns 0 at the end of its data.  Like the reference it
+// decodes as it reads, in bounded memory: a buffer of input (1 MiB to begin with), the last 32 KiB of
+// output as history, and a buffer of output (4 MiB to begin with).  The reference feeds a CPU state machine
+// that can stop at any bit (src/decompress/mod.rs:213-353); the engine's step (rsx_inflate_stream_step)
+// stops between two blocks, so a block must fit the buffers whole: they double when a step makes no
+// progress (the reference's input buffer doubles up to 1 MiB and then fails with "input buffer full",
+// :346-352; here up to 256 MiB).  Bytes and errors are the reference's: BadData -> InvalidData "deflate
+// decompression failed" (:329-333) behind the bytes of the blocks in front of the damage, a stream that
+// ends early -> UnexpectedEof "unexpected EOF" (:359-370) behind everything that could be decoded, an
+// empty reader -> read() returns 0 (:371).
 template <class Reader>
 class DeflateDecoder {
   public:
@@ -469,59 +471,115 @@ class DeflateDecoder {
     // io::Read::read: up to buf.size bytes, 0 at the end of the stream
     size_t read(BytesMut buf)
     {
-        if (!decoded_) decode_all();
-        const size_t count = std::min(buf.size, out_.size() - read_pos_);
-        if (count) std::memcpy(buf.data, out_.data() + read_pos_, count);
-        read_pos_ += count;
+        if (buf.size == 0) return 0;
+        while (out_pos_ == out_len_ && !done_) step();
+        const size_t count = std::min(buf.size, out_len_ - out_pos_);
+        if (count) std::memcpy(buf.data, out_.data() + out_pos_, count);
+        out_pos_ += count;
         return count;
     }
     // everything that is left (io::Read::read_to_end)
     std::vector<uint8_t> read_to_end()
     {
-        if (!decoded_) decode_all();
-        std::vector<uint8_t> rest(out_.begin() + (std::ptrdiff_t)read_pos_, out_.end());
-        read_pos_ = out_.size();
-        return rest;
+        std::vector<uint8_t> rest;
+        for (;;) {
+            while (out_pos_ == out_len_ && !done_) step();
+            if (out_pos_ == out_len_) return rest;
+            rest.insert(rest.end(), out_.begin() + (std::ptrdiff_t)out_pos_, out_.begin() + (std::ptrdiff_t)out_len_);
+            out_pos_ = out_len_;
+        }
     }
+    // bytes of buffer memory the decoder holds at the moment (input, history, output)
+    size_t buffered_bytes() const { return in_.capacity() + hist_.capacity() + out_.capacity(); }
 
   private:
-    void decode_all()
+    static constexpr size_t kMaxBuffer = size_t(256) << 20;
+    // one step of the engine over what has been read so far; called with the output buffer drained
+    void step()
     {
-        decoded_ = true;
-        std::vector<uint8_t> in;
-        for (;;) {   // (the reference's input buffer also doubles as it fills, src/stream.rs:346-352)
-            const size_t at = in.size(), room = std::max<size_t>(32 * 1024, at);
-            in.resize(at + room);
-            const size_t n = inner_(in.data() + at, room);
-            in.resize(at + n);
-            if (n == 0) break;
+        if (failed_) throw Error(fail_kind_, fail_msg_);
+        // top the input up to feed_ bytes
+        if (in_pos_ && (in_pos_ == in_.size() || in_pos_ >= feed_ / 2)) {
+            in_.erase(in_.begin(), in_.begin() + (std::ptrdiff_t)in_pos_);
+            in_pos_ = 0;
         }
-        if (in.empty()) return;   // nothing to decode: read() returns 0
-        if (!engine_) engine_ = Engine::shared();
-        // DEFLATE expands at most 1032 : 1 (a 258-byte match per two bits and a bit)
-        const uint64_t most = (uint64_t)in.size() * 1032 + 65536;
-        for (uint64_t cap = std::max<uint64_t>(4 * (uint64_t)in.size(), 65536);; cap = std::min(2 * cap, most)) {
-            out_.resize((size_t)cap);
-            const uint64_t in_off[2] = {0, in.size()}, out_off[2] = {0, cap};
-            uint64_t size = 0;
-            int32_t status = 0;
-            engine_->check(rsx_batch_decompress(engine_->handle(), RSX_FORMAT_DEFLATE, in.data(), in_off, 1, out_.data(),
-                                                out_off, &size, &status));
-            if (status == RSX_SUCCESS && size <= cap) {
-                out_.resize((size_t)size);
+        while (!eof_ && in_.size() - in_pos_ < feed_) {
+            const size_t at = in_.size(), room = feed_ - (at - in_pos_);
+            in_.resize(at + room);
+            const size_t n = inner_(in_.data() + at, room);
+            in_.resize(at + n);
+            if (n == 0) eof_ = true;
+        }
+        if (in_.size() == in_pos_) {
+            // no input left: an empty reader is an empty stream, anything else ends early (src/stream.rs:355-371)
+            if (!started_) {
+                done_ = true;
                 return;
             }
-            if (status == RSX_INSUFFICIENT_SPACE && cap < most) continue;
-            out_.clear();
-            if (status == RSX_SHORT_INPUT) throw Error(ErrorKind::UnexpectedEof, "unexpected EOF");
-            throw Error(ErrorKind::InvalidData, "deflate decompression failed");
+            fail(ErrorKind::UnexpectedEof, "unexpected EOF");
         }
+        if (!engine_) engine_ = Engine::shared();
+        if (out_.size() < out_cap_) out_.resize(out_cap_);
+        uint64_t next_bit = 0;
+        size_t produced = 0;
+        int32_t status = 0;
+        engine_->check(rsx_inflate_stream_step(engine_->handle(), in_.data() + in_pos_, in_.size() - in_pos_, bit_,
+                                               hist_.data(), hist_.size(), out_.data(), out_cap_, &next_bit, &produced,
+                                               &status));
+        const bool progress = produced != 0 || next_bit != bit_;
+        started_ = started_ || progress || status == RSX_SUCCESS;
+        in_pos_ += (size_t)(next_bit >> 3);
+        bit_ = (uint32_t)(next_bit & 7);
+        out_pos_ = 0;
+        out_len_ = produced;
+        // the history of the next step: the last 32 KiB of everything produced so far
+        if (produced >= 32768) {
+            hist_.assign(out_.begin() + (std::ptrdiff_t)(produced - 32768), out_.begin() + (std::ptrdiff_t)produced);
+        } else if (produced) {
+            const size_t keep = std::min(hist_.size(), 32768 - produced);
+            hist_.erase(hist_.begin(), hist_.end() - (std::ptrdiff_t)keep);
+            hist_.insert(hist_.end(), out_.begin(), out_.begin() + (std::ptrdiff_t)produced);
+        }
+        switch (status) {
+        case RSX_SUCCESS:
+            done_ = true;
+            return;
+        case RSX_SHORT_INPUT:
+            if (progress) return;
+            if (eof_) fail(ErrorKind::UnexpectedEof, "unexpected EOF");
+            if (feed_ >= kMaxBuffer) fail(ErrorKind::Other, "input buffer full");
+            feed_ *= 2;   // the block in front is longer than the buffer
+            return;
+        case RSX_INSUFFICIENT_SPACE:
+            if (progress) return;
+            if (out_cap_ >= kMaxBuffer) fail(ErrorKind::Other, "output buffer full");
+            out_cap_ *= 2;
+            return;
+        default:
+            // damaged data: the bytes of the blocks in front go out first (src/stream.rs:316-333)
+            failed_ = true;
+            fail_kind_ = ErrorKind::InvalidData;
+            fail_msg_ = "deflate decompression failed";
+            if (!produced) throw Error(fail_kind_, fail_msg_);
+            return;
+        }
+    }
+    [[noreturn]] void fail(ErrorKind kind, const char *msg)
+    {
+        failed_ = true;
+        fail_kind_ = kind;
+        fail_msg_ = msg;
+        throw Error(kind, msg);
     }
     Reader inner_;
     std::shared_ptr<Engine> engine_;
-    std::vector<uint8_t> out_;
-    size_t read_pos_ = 0;
-    bool decoded_ = false;
+    std::vector<uint8_t> in_, hist_, out_;
+    size_t in_pos_ = 0, out_pos_ = 0, out_len_ = 0;
+    size_t feed_ = size_t(1) << 20, out_cap_ = size_t(4) << 20;
+    uint32_t bit_ = 0;
+    bool eof_ = false, done_ = false, started_ = false, failed_ = false;
+    ErrorKind fail_kind_ = ErrorKind::Other;
+    const char *fail_msg_ = "";
 };
 
 // crate-level checksums (src/lib.rs:15-17): pass the previous result to continue one

@@ -362,18 +362,60 @@ static void test_stream_decoder()
         const Buf &src = which ? damaged : cut;
         auto reader = reader_over(src, 50000);
         rsx::DeflateDecoder<decltype(reader)> dec(reader);
-        Buf piece(100);
-        // what the oracle says about the stream decides which error it must be
+        // what the oracle says about the stream decides which error it must be; the bytes in front of the
+        // error are the text's (src/stream.rs:316-333: what was decoded goes out before the error does)
         std::vector<uint8_t> scratch(text.size());
         size_t used = 0, produced = 0;
         const int r = orc_decompress(ORC_FMT_DEFLATE, src.data(), src.size(), scratch.data(), scratch.size(), &used, &produced);
+        Buf got, piece(30000);
+        bool threw = false;
         try {
-            dec.read(piece);
-            CHECK(r == 0);
+            for (;;) {
+                const size_t n = dec.read(piece);
+                if (n == 0) break;
+                got.insert(got.end(), piece.begin(), piece.begin() + n);
+            }
         } catch (const rsx::Error &e) {
+            threw = true;
             if (r == 4) CHECK(e.kind() == rsx::ErrorKind::UnexpectedEof && std::string(e.what()) == "unexpected EOF");
             else CHECK(r != 0 && e.kind() == rsx::ErrorKind::InvalidData && std::string(e.what()) == "deflate decompression failed");
         }
+        CHECK(threw == (r != 0));
+        if (r == 0) {   // (damage that still decodes: the oracle's bytes)
+            CHECK(got.size() == produced && std::equal(got.begin(), got.end(), scratch.begin()));
+            continue;
+        }
+        // whole 64 KiB blocks in front of the cut / the damage went out first, and they are the text's
+        const size_t sure = text.size() / 4;
+        CHECK(got.size() >= sure && std::equal(got.begin(), got.begin() + (std::ptrdiff_t)sure, text.begin()));
+        try {   // the error stays
+            dec.read(piece);
+            CHECK(false);
+        } catch (const rsx::Error &) {
+        }
+    }
+    {
+        // bounded memory: a stream of 24 MiB goes through buffers of a few MiB
+        Buf big;
+        for (int k = 0; k < 12; k++) {
+            const Buf t = make_text(2 * 1024 * 1024, 50 + k);
+            big.insert(big.end(), t.begin(), t.end());
+        }
+        const Buf zb = c.compress_deflate(big);
+        auto reader = reader_over(zb, 300000);
+        rsx::DeflateDecoder<decltype(reader)> dec(reader);
+        Buf piece(1 << 20);
+        size_t at = 0, most = 0;
+        bool same = true;
+        for (;;) {
+            const size_t n = dec.read(piece);
+            if (n == 0) break;
+            same = same && at + n <= big.size() && std::equal(piece.begin(), piece.begin() + n, big.begin() + at);
+            at += n;
+            most = std::max(most, dec.buffered_bytes());
+        }
+        CHECK(same && at == big.size());
+        CHECK(most < (12u << 20));
     }
 }
 

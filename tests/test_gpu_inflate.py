@@ -168,30 +168,42 @@ def test_valid_streams_are_decoded_once(eng):
     assert eng.last_fallbacks() == 2
 
 
-def test_streams_of_short_blocks_borrow_token_rows(eng):
-    # zlib at its default memLevel, every strategy, with and without a flush every 20 KB: rounds end where blocks
-    # end, streams of nothing but literals (Z_HUFFMAN_ONLY) and of short blocks use up their share of the token
-    # rows and go on with rows of the batch's shared pool instead of being decoded again by the one-kernel decoder
+def test_streams_of_short_blocks_share_token_rows(eng):
+    # zlib at every memLevel (blocks of 127 symbols at memLevel 1, of 16383 at memLevel 8), every strategy, with and
+    # without a flush every 20 KB: rounds end where blocks end, so streams of short blocks and streams of nothing
+    # but literals (Z_HUFFMAN_ONLY) fill a few columns of a round's token rows.  Rounds share rows (and a stream
+    # that still runs out borrows from the batch's pool): none of these streams may need the one-kernel decoder.
     datas = [corpus.text(300000, 31), corpus.mixed(300000, 32), corpus.json_like(300000, 33), corpus.text(8000, 35)]
-    for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
-        for flush in (None, zlib.Z_SYNC_FLUSH, zlib.Z_BLOCK):
-            streams, caps = [], []
-            for d in datas:
-                for lvl in (1, 6):
-                    co = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, strat)
-                    parts = []
-                    step = len(d) if flush is None else 20000
-                    for at in range(0, len(d), step):
-                        parts.append(co.compress(d[at:at + step]))
-                        if flush is not None:
-                            parts.append(co.flush(flush))
-                    parts.append(co.flush())
-                    streams.append(b"".join(parts))
-                    caps.append(len(d))
-            got, status = eng.batch_decompress(streams, caps, 1)
-            assert [int(x) for x in status] == [0] * len(streams)
-            assert got == [d for d in datas for _ in (1, 6)]
-            assert eng.last_fallbacks() == 0, (strat, flush)
+    for mem in (1, 2, 4, 6, 8, 9):
+        for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+            for flush in (None, zlib.Z_SYNC_FLUSH, zlib.Z_BLOCK):
+                if mem not in (1, 8) and flush == zlib.Z_BLOCK:
+                    continue
+                streams, caps = [], []
+                for d in datas:
+                    for lvl in (1, 6):
+                        co = zlib.compressobj(lvl, zlib.DEFLATED, 15, mem, strat)
+                        parts = []
+                        step = len(d) if flush is None else 20000
+                        for at in range(0, len(d), step):
+                            parts.append(co.compress(d[at:at + step]))
+                            if flush is not None:
+                                parts.append(co.flush(flush))
+                        parts.append(co.flush())
+                        streams.append(b"".join(parts))
+                        caps.append(len(d))
+                got, status = eng.batch_decompress(streams, caps, 1)
+                assert [int(x) for x in status] == [0] * len(streams), (mem, strat, flush)
+                assert got == [d for d in datas for _ in (1, 6)], (mem, strat, flush)
+                assert eng.last_fallbacks() == 0, (mem, strat, flush)
+    # a batch made of nothing but such streams (the pool is a quarter of the batch's own rows)
+    streams = []
+    for k in range(64):
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 1 + k % 3, zlib.Z_HUFFMAN_ONLY if k % 2 else zlib.Z_DEFAULT_STRATEGY)
+        streams.append(co.compress(datas[k % 3]) + co.flush())
+    got, status = eng.batch_decompress(streams, [300000] * 64, 1)
+    assert not any(status) and got == [datas[k % 3] for k in range(64)]
+    assert eng.last_fallbacks() == 0
 
 
 def test_error_codes_match_oracle(eng):

@@ -9,7 +9,7 @@ B="$ROOT/variants/$name"
 mkdir -p "$B"
 pids=()
 for f in api.cpp checksum.hip inflate.hip deflate.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-but-set-variable "$@" -x hip -c "$SRC/$f" -o "$B/$f.o" &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -x hip -c "$SRC/$f" -o "$B/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p" || { rm -rf "$B"; echo "build of variant $name failed"; exit 1; }; done
