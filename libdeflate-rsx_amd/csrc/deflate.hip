@@ -123,7 +123,8 @@ __host__ inline LevelParams level_params(int level)
     // levels 1-6: candidates compared per position (the row's tags drop the hash collisions a
     // chain of the reference's depth 2, 6, 12, 16, 16, 35 spends most of its steps on);
     // levels 7-12: chain steps, the reference's numbers
-    static const uint32_t depth[13] = {0, 2, 4, 4, 6, 6, 8, 100, 300, 600, 35, 100, 300};
+    // (level 1: one probe, the newest entry of the row with the position's tag: HtMatchFinder, matchfinder.rs:1109-1232)
+    static const uint32_t depth[13] = {0, 1, 4, 4, 6, 6, 8, 100, 300, 600, 35, 100, 300};
     static const uint32_t nice[13] = {0, 32, 10, 14, 30, 30, 65, 130, 258, 258, 75, 150, 258};
     LevelParams p;
     p.max_depth = depth[level];
@@ -500,8 +501,10 @@ __device__ inline uint32_t precode_extra_bits(uint32_t sym) { return sym == 16 ?
 // All lanes: Huffman codes of the open block, the block type decision (src/compress/mod.rs:
 // 1375-1398), its header (mod.rs:1775-1883), the tokens, and a fresh block state.
 // in = chunk input, tok = this workgroup's token buffer.
+// static_code: the block is coded with the fixed code of RFC 1951 3.2.6 (level 1, src/compress/mod.rs:1499,
+// :1570-1583: no code construction and a header of three bits).
 __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, bool is_final,
-                            const uint16_t *tok, uint32_t *out_words)
+                            const uint16_t *tok, uint32_t *out_words, bool static_code)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t ntok = L.block_ntok;
@@ -521,11 +524,26 @@ __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, b
     unsigned long long fq = RSX_DEV_TIMERS ? clock64() : 0;
     const bool is_ll = tid < 288, is_off = tid >= 320 && tid < 352;
     const uint32_t osym = tid - 320;
-    huff_collective(is_ll || is_off, is_ll ? tid : osym, is_ll ? 288u : 32u, is_ll ? 14u : 15u,
-                    is_ll ? L.litlen_freq : L.off_freq, is_ll ? L.litlen_len : L.off_len,
-                    is_ll ? L.litlen_code : L.off_code, is_ll ? L.huff_scratch : L.huff_scratch + 288,
-                    is_ll ? L.len_counts[0] : L.len_counts[1], is_ll ? pj : pj + 576,
-                    is_ll ? &L.huff_flag[0] : &L.huff_flag[1], 288u);
+    if (static_code) {
+        // src/compress/mod.rs:153-234: literals 0-143 8 bits from 0x30, 144-255 9 bits from 0x190, 256-279
+        // 7 bits from 0, 280-287 8 bits from 0xC0; offsets 5 bits; codewords stored bit-reversed
+        if (is_ll) {
+            const uint32_t len = tid < 144 ? 8u : tid < 256 ? 9u : tid < 280 ? 7u : 8u;
+            const uint32_t code = tid < 144 ? 0x30u + tid : tid < 256 ? 0x190u + (tid - 144) : tid < 280 ? tid - 256 : 0xC0u + (tid - 280);
+            L.litlen_len[tid] = (uint8_t)len;
+            L.litlen_code[tid] = reverse_bits(code, len);
+        } else if (is_off) {
+            L.off_len[osym] = 5;
+            L.off_code[osym] = reverse_bits(osym, 5);
+        }
+        WG_SYNC();
+    } else {
+        huff_collective(is_ll || is_off, is_ll ? tid : osym, is_ll ? 288u : 32u, is_ll ? 14u : 15u,
+                        is_ll ? L.litlen_freq : L.off_freq, is_ll ? L.litlen_len : L.off_len,
+                        is_ll ? L.litlen_code : L.off_code, is_ll ? L.huff_scratch : L.huff_scratch + 288,
+                        is_ll ? L.len_counts[0] : L.len_counts[1], is_ll ? pj : pj + 576,
+                        is_ll ? &L.huff_flag[0] : &L.huff_flag[1], 288u);
+    }
     if (RSX_DEV_TIMERS && tid == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_deflate_t[6], t_ - fq); fq = t_; }
 
     // ---- lengths to send, cost of the body ------------------------------------------
@@ -546,6 +564,9 @@ __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, b
     WG_SYNC();
     const uint32_t nl = L.nl, no = L.no, total = nl + no;
     auto len_at = [&](uint32_t i) -> uint32_t { return i < nl ? L.litlen_len[i] : L.off_len[i - nl]; };
+    uint32_t nitems = 0, ipos = 0, it = 0, np = 4;
+    uint64_t hdr_bits = 3;   // (the static code: BFINAL and BTYPE)
+    if (!static_code) {
     // ---- run-length items: the first lane of every run of equal lengths writes them ----
     uint32_t mylen = 0;
     bool start = false;
@@ -577,7 +598,6 @@ __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, b
         run = nxt - tid;
         rle_run(mylen, run, [&](uint32_t, uint32_t) { cnt++; });
     }
-    uint32_t nitems;
     uint32_t ioff = wg_exclusive_scan<kET>(L, cnt, &nitems);
     if (start)
         rle_run(mylen, run, [&](uint32_t sym, uint32_t extra) {
@@ -589,15 +609,16 @@ __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, b
     huff_collective(tid < 19, tid, 19u, 7u, L.pre_freq, L.pre_len, L.pre_code, L.huff_scratch,
                     L.len_counts[0], pj, &L.huff_flag[0], 19u);
     if (tid < 19 && L.pre_len[k_precode_perm[tid]]) atomicMax(&L.np, tid + 1);
-    uint32_t it = 0, ibits = 0;
+    uint32_t ibits = 0;
     if (tid < nitems) {
         it = items[tid];
         ibits = L.pre_len[it >> 8] + precode_extra_bits(it >> 8);
     }
     uint32_t items_bits;
-    const uint32_t ipos = wg_exclusive_scan<kET>(L, ibits, &items_bits);
-    const uint32_t np = L.np;
-    const uint64_t hdr_bits = 3 + 5 + 5 + 4 + 3 * np + items_bits;
+    ipos = wg_exclusive_scan<kET>(L, ibits, &items_bits);
+    np = L.np;
+    hdr_bits = 3 + 5 + 5 + 4 + 3 * np + items_bits;
+    }
     const uint64_t body_bits = L.body_bits;
     const uint64_t pos = L.out_bits;
     // as stored blocks of at most 65535 bytes: the first starts at any bit, the others on a byte
@@ -623,8 +644,12 @@ __device__ void flush_block(EmitLds &L, const uint8_t *in, uint32_t block_end, b
             stage_bytes(L, out_words, in + bstart + from, plen);
         }
     } else {
-        if (tid == 0) stage_or(L, pos, (is_final ? 1 : 0) | (2 << 1) | ((nl - 257) << 3) | ((no - 1) << 8) | ((np - 4) << 13), 17);
-        if (tid < np) stage_or(L, pos + 17 + 3 * tid, L.pre_len[k_precode_perm[tid]], 3);
+        if (static_code) {
+            if (tid == 0) stage_or(L, pos, (is_final ? 1 : 0) | (1 << 1), 3);
+        } else {
+            if (tid == 0) stage_or(L, pos, (is_final ? 1 : 0) | (2 << 1) | ((nl - 257) << 3) | ((no - 1) << 8) | ((np - 4) << 13), 17);
+            if (tid < np) stage_or(L, pos + 17 + 3 * tid, L.pre_len[k_precode_perm[tid]], 3);
+        }
         if (tid < nitems) {
             const uint32_t sym = it >> 8, l = L.pre_len[sym];
             stage_or(L, pos + 17 + 3 * np + ipos, L.pre_code[sym] | ((it & 0xFF) << l), l + precode_extra_bits(sym));
@@ -1609,7 +1634,7 @@ __global__ __launch_bounds__(kET, RSX_EMIT_OCC) void deflate_emit_kernel(
     const uint32_t *__restrict__ chunk_first, uint32_t chunk_slots, int stored_only,
     uint8_t *__restrict__ scratch, uint64_t scratch_stride, const uint16_t *__restrict__ tokbuf, uint64_t tok_stride,
     const uint2 *__restrict__ blk_tab, const uint16_t *__restrict__ blk_hist,
-    const uint32_t *__restrict__ chunk_blocks, uint32_t *__restrict__ chunk_size, int finish)
+    const uint32_t *__restrict__ chunk_blocks, uint32_t *__restrict__ chunk_size, int finish, int static_code)
 {
     __shared__ EmitLds L;
     const uint32_t tid = threadIdx.x;
@@ -1674,7 +1699,7 @@ __global__ __launch_bounds__(kET, RSX_EMIT_OCC) void deflate_emit_kernel(
                     L.block_start = start;
                 }
                 WG_SYNC();
-                flush_block(L, src, e.x, last_chunk && k + 1 == nb, tok + unit0, out_words);
+                flush_block(L, src, e.x, last_chunk && k + 1 == nb, tok + unit0, out_words, static_code != 0);
                 start = e.x;
                 unit0 += e.y;
             }
@@ -1961,7 +1986,7 @@ int deflate_launch(rsx_engine *e, int format, int level, const uint8_t *in, cons
         deflate_emit_kernel<<<emit_grid, kET, 0, e->stream>>>(in, in_off, (uint32_t)n, chunk_first, (uint32_t)chunks,
                                                                level == 0, scratch, stride, tokbuf, tok_units, blk_tab,
                                                                blk_hist, chunk_blocks, chunk_size,
-                                                               flush == RSX_FLUSH_FINISH);
+                                                               flush == RSX_FLUSH_FINISH, level == 1);
     }
     e->timed = true;
     RSX_HIP(e, hipGetLastError());

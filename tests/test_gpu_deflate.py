@@ -112,6 +112,21 @@ def test_level_ordering_and_ratio_vs_oracle(eng):
             assert got <= limit * ref, (kind, level, got, ref)
 
 
+def test_level_one_uses_the_static_code(eng):
+    # src/compress/mod.rs:1499-1583: level 1 codes every block with the fixed code of RFC 1951 (BTYPE = 01) behind
+    # a single-probe match finder (matchfinder.rs:1109-1232); blocks that do not pay are still stored
+    datas = [corpus.text(1 << 20, 61), corpus.mixed(1 << 20, 62), corpus.json_like(1 << 20, 63), corpus.text(3000, 64)]
+    comp = roundtrip(eng, datas, 0, 1)
+    for d, c in zip(datas, comp):
+        assert (c[0] >> 1) & 3 in (1, 0)            # first block: static (or stored)
+        ref = o.compress(d, 1)
+        assert (ref[0] >> 1) & 3 == 1
+        assert len(c) <= 1.06 * len(ref), (len(c), len(ref))
+    assert (comp[0][0] >> 1) & 3 == 1 and (comp[3][0] >> 1) & 3 == 1
+    roundtrip(eng, datas, 1, 1)
+    roundtrip(eng, datas, 2, 1)
+
+
 def test_cost_based_levels(eng):
     # levels 10-12 (src/compress/mod.rs:1586-1773): valid streams in every format, no larger
     # than the lazy parse with the deepest search, and within 3 % of the oracle's restatement
