@@ -549,6 +549,13 @@ static unsigned ht_find_match(orc_compressor *c, const uint8_t *data, size_t len
     return match_len(m, src, maxl);
 }
 
+/* test hook: huffman_comp.rs:125-155 on a caller's frequencies (lens and codewords hold num_syms entries) */
+void orc_make_huffman_code(unsigned num_syms, unsigned max_len, const uint32_t *freqs, uint8_t *lens,
+                           uint32_t *codewords)
+{
+    make_huffman_code(num_syms, max_len, freqs, lens, codewords);
+}
+
 void orc_hc_find_match_kat(const uint8_t *data, size_t len, size_t pos, int max_depth,
                            int nice_len, int *out_len, int *out_offset)
 {

@@ -75,6 +75,9 @@ int orc_compress_raw(orc_compressor *c, const uint8_t *in, size_t in_len, uint8_
 /* hash-chain match finder probe for the reference's unit KAT
  * (src/compress/matchfinder.rs:1783-1814): insert positions [0,pos) then
  * search at pos. */
+/* make_huffman_code (huffman_comp.rs:125-155): length-limited canonical code for `freqs`; codewords bit-reversed */
+void orc_make_huffman_code(unsigned num_syms, unsigned max_len, const uint32_t *freqs, uint8_t *lens,
+                           uint32_t *codewords);
 void orc_hc_find_match_kat(const uint8_t *data, size_t len, size_t pos, int max_depth,
                            int nice_len, int *out_len, int *out_offset);
 

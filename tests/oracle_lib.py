@@ -50,6 +50,7 @@ def lib():
                                        C.POINTER(C.c_size_t)]
         L.orc_hc_find_match_kat.argtypes = [u8p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_make_huffman_code.argtypes = [C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_batch_compress.argtypes = [C.c_int, C.c_int, u8p, u64p, C.c_size_t, u8p, u64p,
                                          u64p, i32p, C.c_int]
         L.orc_batch_decompress.argtypes = [C.c_int, u8p, u64p, C.c_size_t, u8p, u64p, u64p,
@@ -157,3 +158,12 @@ def batch_decompress(flat, in_off, out_off, fmt, threads=8):
                                n, out.ctypes.data, out_off.ctypes.data, sizes.ctypes.data,
                                status.ctypes.data, threads)
     return out, sizes, status
+
+
+def make_huffman_code(freqs, max_len):
+    """huffman_comp.rs:125-155 -> (code lengths, bit-reversed codewords) for the given symbol frequencies."""
+    f = np.ascontiguousarray(np.asarray(freqs, dtype=np.uint32))
+    lens = np.zeros(len(f), dtype=np.uint8)
+    codes = np.zeros(len(f), dtype=np.uint32)
+    lib().orc_make_huffman_code(len(f), max_len, f.ctypes.data, lens.ctypes.data, codes.ctypes.data)
+    return lens, codes

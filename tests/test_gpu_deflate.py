@@ -112,6 +112,33 @@ def test_level_ordering_and_ratio_vs_oracle(eng):
             assert got <= limit * ref, (kind, level, got, ref)
 
 
+def test_code_lengths_are_the_reference_algorithms(eng):
+    # make_huffman_code (src/compress/huffman_comp.rs:125-155): the code lengths in the dynamic headers the engine
+    # writes are the ones the oracle's restatement computes for the same symbol frequencies (the frequencies are
+    # counted from the block bodies by an independent DEFLATE walker), length limiting included: the skewed
+    # buffer has symbols 2^-18 as frequent as the commonest, whose unlimited codewords would be longer than 14 bits
+    import deflate_walk
+    rs = np.random.RandomState(5)
+    p = 0.55 ** np.arange(40, dtype=np.float64)
+    skewed = rs.choice(40, size=60000, p=p / p.sum()).astype(np.uint8).tobytes()
+    datas = [corpus.text(200000, 71), corpus.mixed(150000, 72), corpus.json_like(120000, 73), skewed]
+    checked = limited = 0
+    for level in (2, 6, 9):
+        comp, st = eng.batch_compress(datas, 0, level)
+        for c in comp:
+            for blk in deflate_walk.walk(c):
+                if blk["type"] != 2:
+                    continue
+                for lens_key, freq_key, nsym, max_len in (("litlen_lens", "litlen_freq", 288, 14),
+                                                          ("offset_lens", "offset_freq", 32, 15)):
+                    want, _ = o.make_huffman_code(blk[freq_key][:nsym], max_len)
+                    got = list(blk[lens_key]) + [0] * (nsym - len(blk[lens_key]))
+                    assert got == [int(x) for x in want], (level, lens_key)
+                    limited += max(got) == max_len
+                checked += 1
+    assert checked >= 20 and limited >= 1
+
+
 def test_level_one_uses_the_static_code(eng):
     # src/compress/mod.rs:1499-1583: level 1 codes every block with the fixed code of RFC 1951 (BTYPE = 01) behind
     # a single-probe match finder (matchfinder.rs:1109-1232); blocks that do not pay are still stored

@@ -221,3 +221,24 @@ def test_near_optimal_levels():
     assert len(o.compress(a, 12)) <= len(o.compress(a, 1)) < len(o.compress(a, 0))
     for fmt, wb in ((o.FMT_ZLIB, 15), (o.FMT_GZIP, 31)):
         assert zlib.decompress(o.compress(datas[0], 12, fmt), wb) == datas[0]
+
+
+def test_dynamic_headers_carry_make_huffman_code_lengths():
+    # huffman_comp.rs:125-155 through the test hook: the code lengths in the oracle's own dynamic headers are the
+    # ones make_huffman_code gives for the frequencies counted from the block bodies by the tests' DEFLATE walker
+    import corpus
+    import deflate_walk
+    for level in (2, 6, 9):
+        stream = o.compress(corpus.text(150000, 5) + corpus.mixed(80000, 6), level)
+        blocks = [b for b in deflate_walk.walk(stream) if b["type"] == 2]
+        assert blocks
+        for b in blocks:
+            for key, fkey, nsym, max_len in (("litlen_lens", "litlen_freq", 288, 14), ("offset_lens", "offset_freq", 32, 15)):
+                want, _ = o.make_huffman_code(b[fkey][:nsym], max_len)
+                got = list(b[key]) + [0] * (nsym - len(b[key]))
+                assert got == [int(x) for x in want]
+    # the degenerate codes of :133-145: no symbol, one symbol
+    lens, codes = o.make_huffman_code([0] * 32, 15)
+    assert list(lens[:2]) == [1, 1] and not lens[2:].any()
+    lens, codes = o.make_huffman_code([0] * 7 + [9] + [0] * 24, 15)
+    assert lens[0] == 1 and lens[7] == 1 and int(lens.sum()) == 2
