@@ -326,8 +326,9 @@ def bench_decompress(args, ctx):
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level)),
-            "traffic_all_kernels": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level), "all_kernels"),
+            # (kernel_ms spans every kernel of the call, and so does the traffic)
+            "traffic": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level), "all_kernels"),
+            "traffic_decoder_kernels": measured_traffic("decompress:%dx%dKiB:gzip:%d" % (n, args.buf_kib, level)),
             "kernel": "inflate_decode_kernel + inflate_expand_kernel (dependent launches; kernel_ms spans the whole call: the marker search that cuts the streams into parts, both decoder kernels, the CRC-32 pass and the trailer check)",
             "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
         },
@@ -401,9 +402,8 @@ def bench_compress(args, ctx):
                    "compressed_ratio": total_in / total_out, "verified": ok},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level)),
-                     "traffic_all_kernels": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level),
-                                                             "all_kernels"),
+                     "traffic": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level), "all_kernels"),
+                     "traffic_match_and_emit_kernels": measured_traffic("compress:%dx%dKiB:%s:%d" % (n, args.buf_kib, args.corpus, level)),
                      "kernel": "deflate_chunks_kernel (dominant; kernel_ms spans the whole call: match, emit, checksum, plan, place)", "kernel_ms": k_ms,
                      "algorithmic_bytes": total_in + total_out},
     }

@@ -66,7 +66,22 @@ with open("%s/counters_per_kernel.csv" % dest, "w") as f:
     w.writerow(["bench", "kernel", "counter", "per_batch", "dispatches", "batches"])
     for r in rows_out:
         w.writerow([r[0], r[1], r[2], "%.6g" % r[3], r[4], r[5]])
+for tag in ("decompress64k", "compressl12", "compressl1"):   # the other shapes: kernel statistics and bench lines
+    found = glob.glob("%s/%s_stats/**/*kernel_stats.csv" % (base, tag), recursive=True)
+    if found:
+        f = sorted(found, key=os.path.getmtime)[-1]
+        shutil.copy(f, "%s/%s_kernel_stats.csv" % (dest, tag))
+        shutil.copy("%s/%s_bench_line.json" % (base, tag), "%s/%s_bench_line.json" % (dest, tag))
+        for r in list(csv.DictReader(open(f)))[:3]:
+            print(tag, short(r["Name"])[:48], r["Calls"], "%.3f ms" % (float(r["AverageNs"]) / 1e6))
+sys.path.insert(0, ".")
+import bench  # noqa: E402  (the hash of the kernel sources the counters belong to)
 j = json.load(open("bench_traffic.json"))
+j["csrc_sha16"] = bench.kernel_sources_hash()
+j["_comment"] = ("HBM bytes per batch from separate rocprofv3 --pmc passes (profiles/%s/counters_per_kernel.csv): 2 x FETCH_SIZE "
+                 "(gfx950 counts half of 16-byte-per-lane reads) + WRITE_SIZE, both in KiB; dominant_kernels = the decoder / match "
+                 "and emit kernels, all_kernels = every kernel of the call; valid for the default workloads and for the kernel "
+                 "sources whose hash is csrc_sha16" % rnd)
 j["decompress:4096x1024KiB:gzip:6"] = {"dominant_kernels": int(traffic["decompress"][0]), "all_kernels": int(traffic["decompress"][1])}
 j["compress:4096x1024KiB:mixed:6"] = {"dominant_kernels": int(traffic["compress"][0]), "all_kernels": int(traffic["compress"][1])}
 with open("bench_traffic.json", "w") as f:
