@@ -15,30 +15,32 @@
 // (the reference has no stored fallback above level 0).  The contract is a valid
 // stream of the same format that inflates to the input.
 //
-// One 1024-thread workgroup per CU (156 KiB of LDS) compresses one 256 KiB chunk at a time:
-//   match   positions are taken 1024 at a time.  Each lane hashes its 4 bytes (and
-//           its 3 bytes, for a table of the newest length-3 candidates), pushes its
-//           position on the hash chain (head and distance-link tables in LDS, one
-//           LDS atomic exchange per position, waves in turn so chains stay ordered)
-//           and walks the chain of older positions, comparing 20 bytes per candidate
-//           against its own first 20 bytes held in registers; the input window is a
-//           sliding LDS copy;
-//   parse   greedy / lazy selection is a pointer chase p -> next(p); the set of
-//           token starts is found by pointer jumping (at most log2(1024) rounds,
-//           fewer when the entry's pointer leaves the batch early), a prefix sum
-//           places the tokens in a per-workgroup token buffer and LDS atomics build
-//           the symbol histograms;
-//   emit    per <= 64 KiB block the workgroup builds the Huffman codes and the
-//           header together, then all lanes compute token bit lengths, prefix-sum
-//           them and pack their code bits into the output words.
-// Levels 10-12 run the batch loop twice around a cost-based parse (see
-// optimal_parse_piece); the kernel is compiled separately for them.
-// A second kernel concatenates the chunks of each item behind the container
-// header (or writes the item as plain stored blocks when that is smaller), adds
-// the Adler-32 / CRC-32 trailer and reports sizes and status.
+// deflate_chunks_kernel: one 1024-thread workgroup per CU (148 KB of LDS), persistent over the batch's 256 KiB
+// chunks (taken from a counter), matching and parsing only.  Positions are taken 1024 at a time:
+//   insert  a lane loads its 20 bytes and the 8 in front of them from the sliding LDS copy of the input, tests
+//           distances 1..8 in registers and pushes its position: levels 1-6 into a table of 2048 rows x 12 tagged
+//           entries (the newest position wins a slot by an LDS atomic max, so the table does not depend on the
+//           order the lanes arrive in), levels 7-12 on the reference's hash chains (heads + 16-bit links in the
+//           same LDS, pushed wave after wave so that chains stay ordered);
+//   search  candidates nearest first -- the row's entries with the position's tag (1/4/4/6/6/8 of them for
+//           levels 1-6) or a chain walk of the reference's depth -- each tested at the one byte it must match to
+//           beat the best so far, then compared over 20 bytes in registers, longer matches extended in LDS;
+//   parse   greedy / one-step / two-step lazy selection as a pointer chase p -> next(p): every wave squares the
+//           pointers of its 64 positions through lane exchanges and follows the other waves' exits (one barrier);
+//           token units (16 bits: a literal, or a length unit and a distance unit) are compacted by a prefix sum,
+//           staged in LDS and stored as 16-byte pieces; LDS atomics keep the symbol histograms;
+//   blocks  end at 64 KiB, at the chunk end and (levels 7-12) where the token statistics change
+//           (should_end_block); a closed block leaves a table entry and its histogram.
+// Levels 10-12 run the batch loop twice around a cost-based parse over recorded match lists (optimal_parse_piece).
+// deflate_emit_kernel: one 512-thread workgroup per chunk, four per CU: per block the Huffman codes
+// (make_huffman_code spread over the lanes; level 1: the static code), the block type decision, the header
+// and the token bits (prefix sum of bit counts, ORs into an LDS stage, 16-byte stores).
+// deflate_plan_kernel / deflate_place_kernel: the item's chunks back to back behind the container header, or
+// the item as plain stored blocks when that is smaller; Adler-32 / CRC-32 trailer (checksum.hip), size, status.
 //
-// Roofline: HBM by design (algorithmic bytes per item = uncompressed_len +
-// compressed_len); in practice bound by LDS round trips of the chain walk.
+// Roofline: HBM by design (algorithmic bytes per item = uncompressed_len + compressed_len); in practice the match
+// kernel is bound by vector-instruction issue in its search phase and by the barriers of a CU that holds one
+// workgroup.
 #include "engine.h"
 
 #include <cstdlib>
