@@ -167,3 +167,37 @@ def test_gzip_header_crc_is_verified_on_request(rsx):
     got, st = eng.batch_decompress([ko], [len(big)], rsx.FORMAT_GZIP)
     assert list(st) == [0] and got == [big]
     eng.close()
+
+
+def test_calls_from_several_threads(rsx):
+    """compress_batch / decompress_batch take &self and the reference's types are Sync (src/batch.rs:20, :74): calls
+    from several threads on one engine serialise on its lock, calls on engines of their own run side by side; either
+    way every caller gets its own results."""
+    import threading
+    shared = rsx.Engine(0)
+    multi = rsx.Engine(devices=[0, 0])
+    sets = [[corpus.text(200000 + 1000 * t, 100 + t), corpus.mixed(90000, 200 + t), b"", bytes([t]) * 5000] for t in range(6)]
+    errors = []
+
+    def work(t, eng):
+        try:
+            for fmt in (rsx.FORMAT_ZLIB, rsx.FORMAT_GZIP):
+                comp, st = eng.batch_compress(sets[t], fmt, 6)
+                assert list(st) == [0] * len(sets[t])
+                got, st = eng.batch_decompress(comp, [len(d) for d in sets[t]], fmt)
+                assert list(st) == [0] * len(sets[t]) and got == sets[t]
+                crc = eng.batch_checksum(sets[t], rsx.CHECKSUM_CRC32)
+                assert [int(c) for c in crc] == [zlib.crc32(d) for d in sets[t]]
+        except Exception as e:   # noqa: BLE001 (reported by the main thread)
+            errors.append((t, repr(e)))
+
+    own = [rsx.Engine(0) for _ in range(2)]
+    engines = [shared, shared, shared, multi, own[0], own[1]]
+    threads = [threading.Thread(target=work, args=(t, engines[t])) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors, errors
+    for e in own + [shared, multi]:
+        e.close()
