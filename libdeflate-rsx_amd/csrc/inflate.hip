@@ -476,7 +476,7 @@ struct StreamCtx {
 
 // Stage kWinBytes of compressed input around the current bit position.  Returns
 // (through *win_bit0) the body-relative bit position of window bit 0.
-template <class LS>
+template <class LS, int kThreads = kT>
 __device__ inline void stage_window(LS &L, const StreamCtx &c, int64_t *win_bit0)
 {
     constexpr uint32_t kWinBytes = LS::kWinBytes, kWinWords = LS::kWinWords;
@@ -489,11 +489,11 @@ __device__ inline void stage_window(LS &L, const StreamCtx &c, int64_t *win_bit0
     // unit never crosses a page); bytes at or after the end of the body read as 0
     const uint8_t *alloc_lo = c.in_alloc - ((uintptr_t)c.in_alloc & 15);
     const uint8_t *alloc_hi = c.in_alloc + c.in_alloc_len;
-    constexpr uint32_t kUnits = kWinBytes / 16, kPerLane = (kUnits + kT - 1) / kT;
+    constexpr uint32_t kUnits = kWinBytes / 16, kPerLane = (kUnits + kThreads - 1) / kThreads;
     uint4 v[kPerLane];
 #pragma unroll
     for (uint32_t i = 0; i < kPerLane; i++) {   // (every load is issued before the first one is needed)
-        const uint32_t u = threadIdx.x + i * kT;
+        const uint32_t u = threadIdx.x + i * kThreads;
         const uint8_t *unit = wbase + 16 * (size_t)u;
         v[i] = make_uint4(0, 0, 0, 0);
         if (u < kUnits && unit >= alloc_lo && unit < alloc_hi && unit < body_end)
@@ -501,7 +501,7 @@ __device__ inline void stage_window(LS &L, const StreamCtx &c, int64_t *win_bit0
     }
 #pragma unroll
     for (uint32_t i = 0; i < kPerLane; i++) {
-        const uint32_t u = threadIdx.x + i * kT;
+        const uint32_t u = threadIdx.x + i * kThreads;
         const uint8_t *unit = wbase + 16 * (size_t)u;
         if (unit < body_end && unit + 16 > body_end) {
             uint32_t keep = (uint32_t)(body_end - unit);  // 1..15 valid bytes
@@ -1746,7 +1746,15 @@ __global__ __launch_bounds__(kT, 5) void inflate_kernel(
 constexpr int32_t kStatusPending = -2;    // decoded into tokens, not expanded yet
 constexpr int32_t kStatusFallback = -3;   // left to inflate_kernel
 constexpr int32_t kStatusChain = -5;      // a part that copies from the part in front of it / a stream with such parts
-constexpr uint32_t kTokCap = 96;          // tokens per sub-sequence and round
+// The first kernel runs kDT threads per stream: a round has at most kDT sub-sequences, each a column of its token
+// rows (rows are kT words wide whatever kDT is: rounds share them side by side).  Fewer, longer sub-sequences
+// spend a smaller share of the decoder's steps on the warm-up in front of a sub-sequence.
+#ifndef RSX_DEC_THREADS
+#define RSX_DEC_THREADS 256
+#endif
+constexpr int kDT = RSX_DEC_THREADS;
+static_assert(kDT == 256 || kDT == 128, "whole waves, and the rows hold a whole number of rounds side by side");
+constexpr uint32_t kTokCap = 96 * (kT / kDT);   // tokens per sub-sequence and round
 constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence in pieces of this many steps
 constexpr uint32_t kSegRows = kTokCap / kSegSteps - 1;   // header rows 1..kSegRows: bytes | matches << 16 in front of piece p
 constexpr uint32_t kHdrRows = 1 + kSegRows;
@@ -1761,7 +1769,7 @@ static_assert(kTokCap <= kMaxMatches, "one sub-sequence must fit the match queue
 // with an odd stride the 64 lanes of a wave start in 64 different LDS banks (448 bits = 14 words: two lanes
 // per bank, 4.69 ms for the bench's decode kernel; 480 bits: 4.32 ms; 512 bits, 16 lanes per bank: 5.02 ms).
 #ifndef RSX_DEC_SUB_BITS
-#define RSX_DEC_SUB_BITS 480
+#define RSX_DEC_SUB_BITS (RSX_DEC_THREADS == 256 ? 480 : 992)
 #endif
 #ifndef RSX_DEC_WARM_BITS
 #define RSX_DEC_WARM_BITS 1024
@@ -1769,7 +1777,7 @@ static_assert(kTokCap <= kMaxMatches, "one sub-sequence must fit the match queue
 constexpr uint32_t kDecSubMax = RSX_DEC_SUB_BITS;      // longest sub-sequence (bits)
 constexpr uint32_t kDecSubMin = 32;
 constexpr uint32_t kDecWarm = RSX_DEC_WARM_BITS;
-constexpr uint32_t kDecWinBytes = (kT * kDecSubMax / 8 + 256 + 15) / 16 * 16;   // the window of one round
+constexpr uint32_t kDecWinBytes = (kDT * kDecSubMax / 8 + 256 + 15) / 16 * 16;   // the window of one round
 constexpr uint32_t kExitFull = 1u << 29;  // the sub-sequence stopped early: token or byte limit
 
 enum { ROUND_END = 0, ROUND_TOKENS = 1, ROUND_STORED = 2 };
@@ -1881,6 +1889,7 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
     if (bound > kWinLimitBits) bound = kWinLimitBits;
     uint32_t n_active = (kWinLimitBits - b0 + sub_bits - 1) / sub_bits;
     if (n_active > max_lanes) n_active = max_lanes;
+    if (n_active > (uint32_t)kDT) n_active = kDT;
     if ((uint32_t)tid >= n_active) bound = lo;   // (a lane without a column decodes nothing)
     uint32_t *col = rows + tid;        // this lane's word of the first header row
 
@@ -1902,7 +1911,7 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
     WG_SYNC();
     if (RSX_SPLIT_TIMERS && tid == 64) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(3, t - tq); tq = t; }
     // passes until every sub-sequence starts where its predecessor ended (as decode_round_parallel)
-    for (int pass = 0; pass <= kT; pass++) {
+    for (int pass = 0; pass <= kDT; pass++) {
         WG_SYNC();
         uint32_t ns = guess;
         if (tid > 0) {
@@ -1917,7 +1926,7 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
         if (need) L.tspec.sub_start[tid] = start;
         WG_SYNC();
         uint32_t before = 0, total = 0;
-        for (int k = 0; k < kT / 64; k++) {
+        for (int k = 0; k < kDT / 64; k++) {
             const uint32_t cnt = L.scan_carry[k];
             if (k < w) before += cnt;
             total += cnt;
@@ -1971,9 +1980,13 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
         L.scan_carry[8 + (tid >> 6)] = by;
     }
     WG_SYNC();
-    mx = max(max(L.scan_carry[0], L.scan_carry[1]), max(L.scan_carry[2], L.scan_carry[3]));
-    tk = L.scan_carry[4] + L.scan_carry[5] + L.scan_carry[6] + L.scan_carry[7];
-    by = L.scan_carry[8] + L.scan_carry[9] + L.scan_carry[10] + L.scan_carry[11];
+    mx = tk = by = 0;
+#pragma unroll
+    for (int k = 0; k < kDT / 64; k++) {
+        mx = max(mx, L.scan_carry[k]);
+        tk += L.scan_carry[4 + k];
+        by += L.scan_carry[8 + k];
+    }
     const uint32_t last_exit = L.tspec.lane_exit[last];
     WG_SYNC();
     const uint32_t consumed = (last_exit & kExitPosMask) - b0;
@@ -2009,7 +2022,7 @@ __device__ uint32_t decode_round_tokens(DecodeLds &L, const StreamCtx &c, int64_
 }
 
 #ifndef RSX_DEC_OCC
-#define RSX_DEC_OCC 6
+#define RSX_DEC_OCC (RSX_DEC_THREADS == 256 ? 6 : 3)
 #endif
 // parts != nullptr: the items are the parts of cut streams (see "Streams cut into parts" below): *parts->count
 // of them, the ones marked kStatusFallback beforehand are left alone, a part with open_end set ends well when
@@ -2019,7 +2032,7 @@ struct DecodeParts {
     const uint8_t *open_end;
     uint64_t *bytes;
 };
-__global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
+__global__ __launch_bounds__(kDT, RSX_DEC_OCC) void inflate_decode_kernel(
     int format, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint32_t n,
     uint64_t total_in, int32_t *__restrict__ status, uint64_t *__restrict__ body_end, SplitLayout lay,
     const uint64_t *__restrict__ in_hi, const uint64_t *__restrict__ in_base_p, DecodeParts parts)
@@ -2100,7 +2113,7 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
         int64_t win_bit0;
         unsigned long long ts = SPLIT_T_NOW();
         (void)ts;   // (read only by the phase timers of development builds)
-        stage_window(L, c, &win_bit0);
+        stage_window<DecodeLds, kDT>(L, c, &win_bit0);
         WG_SYNC();
         if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(0, t - ts); ts = t; }
         if (!L.in_block) {
@@ -2154,13 +2167,13 @@ __global__ __launch_bounds__(kT, RSX_DEC_OCC) void inflate_decode_kernel(
             }
             uint32_t *const rows_at = (chunk ? lay.tok + (lay.pool_first + (chunk - 1)) * kT : tok) + row * kT + col0;
             uint32_t nlanes = 0, sub_next = sub_bits, round_bytes = 0;
-            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, rows_at, (uint32_t)kT - col0, &nlanes,
-                                                      &sub_next, &round_bytes);
+            const uint32_t used = decode_round_tokens(L, c, win_bit0, sub_bits, rows_at, min((uint32_t)kDT, (uint32_t)kT - col0),
+                                                      &nlanes, &sub_next, &round_bytes);
             // A sub-sequence near the round's front that ran into the token or byte limit ends the round there: the
             // round owns a full set of rows for a few sub-sequences' worth of input.  Where the stream has rows to
             // spare that is the cheaper way; where it has not (a short stream, the end of a share) the round is not
             // recorded: the position goes back and the same bits are decoded again with sub-sequences half as long.
-            const bool front_full = (nlanes >> 31) && (nlanes & 0x7FFFFFFFu) * 4 < (uint32_t)kT;
+            const bool front_full = (nlanes >> 31) && (nlanes & 0x7FFFFFFFu) * 4 < (uint32_t)kDT;
             nlanes &= 0x7FFFFFFFu;
             if (front_full && sub_bits > kDecSubMin && row + 2 * (kHdrRows + kTokCap) > row_budget) {
                 sub_bits = max(kDecSubMin, (((sub_bits >> 6) - 1) | 1u) << 5);
@@ -2932,7 +2945,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
         part_finish_kernel<<<(pgrid + tb - 1) / tb, tb, 0, e->stream>>>(grid, count, body_hi, part_lo, part_parent, part_hi,
                                                                         part_open, part_status, parent_first, part_inner);
         // the parts are raw DEFLATE items given as slices; their token rows are laid out by their own numbers
-        inflate_decode_kernel<<<pgrid, kT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, total_in,
+        inflate_decode_kernel<<<pgrid, kDT, 0, e->stream>>>(RSX_FORMAT_DEFLATE, in, part_lo, pgrid, total_in,
                                                            part_status, part_used, lay, part_hi, in_off,
                                                            DecodeParts{count, part_open, part_bytes});
         part_place_kernel<<<(grid + tb - 1) / tb, tb, 0, e->stream>>>(out_off, grid, count, parent_first, part_parent,
@@ -2952,7 +2965,7 @@ int inflate_launch(rsx_engine *e, int format, const uint8_t *in, const uint64_t 
                                                           status, body_end, nullptr, kStatusFallback, in_hi, out_hi,
                                                           in_base_p, taken, ResumeArgs{});
     } else if (split) {
-        inflate_decode_kernel<<<grid, kT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
+        inflate_decode_kernel<<<grid, kDT, 0, e->stream>>>(format, in, in_off, grid, total_in, status, body_end, lay,
                                                           in_hi, in_base_p, DecodeParts{nullptr, nullptr, nullptr});
         inflate_expand_kernel<false><<<grid, kT, 0, e->stream>>>(fmt, in, in_off, grid, out, out_off, out_sizes, status,
                                                                  lay, in_hi, out_hi, in_base_p, nullptr, ExpandChain{});
