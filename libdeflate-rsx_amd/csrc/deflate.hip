@@ -446,7 +446,9 @@ __device__ unsigned long long g_deflate_t[16];
 #define DT_MARK(k) do { if (RSX_DEV_TIMERS && threadIdx.x == 0) { unsigned long long t_ = clock64(); dt[k] += t_ - tq; tq = t_; } } while (0)
 
 // exclusive prefix sum over a workgroup of kThreads lanes (returns the total through *total)
-template <int kThreads, class LS>
+// kIdle: nobody can still be reading the sums of the scan before this one (a barrier lies between), so the
+// barrier in front of writing them is left out
+template <int kThreads, bool kIdle = false, class LS>
 __device__ inline uint32_t wg_exclusive_scan(LS &L, uint32_t v, uint32_t *total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -455,7 +457,7 @@ __device__ inline uint32_t wg_exclusive_scan(LS &L, uint32_t v, uint32_t *total)
         uint32_t y = __shfl_up(x, o);
         if (lane >= o) x += y;
     }
-    WG_SYNC();
+    if (!kIdle) WG_SYNC();
     if (lane == 63) L.scan_tmp[w] = x;
     WG_SYNC();
     uint32_t before = 0, all = 0;
@@ -1215,8 +1217,6 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
                     key[k / 2] = __builtin_bit_cast(u16x2, k16[0] | (k16[1] << 16));
                 }
                 uint32_t depth = 0;
-                // the byte a candidate must match to be longer than the best so far
-                uint32_t next_byte = best_len ? L.inbuf[src_at + best_len] : 0;
                 // Nearest first: the smallest key not yet taken.  Keys minus (last taken + 1), modulo
                 // 2^16, keep the order of the keys that are left and push the taken ones above them.
                 uint32_t taken = 0;   // last taken key + 1
@@ -1232,13 +1232,12 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
                     taken = d0;
                     depth++;
                     it_row++;
-                    if (best_len && L.inbuf[src_at - d0 + best_len] != next_byte) continue;
+                    // (testing first the one byte that a longer match must have costs an LDS round trip of
+                    // its own: 159.8 ms per batch of 4096 x 1 MiB with the test, 156.5 without)
                     uint32_t w[5];
                     it_full++;
                     lds_bytes<5>(L.inbuf, src_at - d0, w);
-                    const uint32_t before_len = best_len;
                     consider(finish_length(w, d0), d0);
-                    if (best_len != before_len && best_len < max_len) next_byte = L.inbuf[src_at + best_len];
                 }
             }
             if (RSX_DEV_TIMERS) {
@@ -1411,8 +1410,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
         const uint32_t my_units = live ? u0 + u1 + u2 : 0;
         uint32_t cnt = my_units + (livex ? units_of(x_t0) : 0);
         uint32_t total;
-        uint32_t at = wg_exclusive_scan<kCT>(L, cnt, &total);
-        const uint32_t tbase = L.tok_base + L.block_ntok, ta = tbase & 7;   // units of the chunk so far
+        // (the scan before this one was the batch before's: barriers lie between)
+        uint32_t at = wg_exclusive_scan<kCT, true>(L, cnt, &total);
+        const uint32_t tok_base = L.tok_base, tbase = tok_base + L.block_ntok, ta = tbase & 7;   // units of the chunk so far
         if ((uint32_t)tid < ta) ustage[tid] = L.tok_tail[tid];
         if (live) {
             put_units(ta + at, t0);
@@ -1442,19 +1442,24 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
                 reinterpret_cast<uint4 *>(tok + (tbase - ta))[tid] = reinterpret_cast<const uint4 *>(ustage)[tid];
             if ((uint32_t)tid < (have & 7)) L.tok_tail[tid] = ustage[(have & ~7u) + tid];
         }
+        // The batch's results: where the next token starts and the units of the open block.  Every lane works
+        // them out for itself (the hand-over slot was written in front of the barrier above); the first lane
+        // also leaves them in LDS for the next batch, which reads them behind barriers of its own, so no
+        // barrier follows here.
+        const uint32_t covered = total ? L.next_entry : entry;   // every byte below is inside an emitted token
+        const uint32_t open_ntok = tbase - tok_base + total;
         if (tid == 0) {
-            if (total) L.entry = L.next_entry;
-            L.block_ntok = tbase - L.tok_base + total;
+            L.entry = covered;
+            L.block_ntok = open_ntok;
             // carry the last position's match to slot 0 of the next batch
             L.m_len[0] = L.m_len[kCT];
             L.m_off[0] = L.m_off[kCT];
         }
-        WG_SYNC();
         DT_MARK(4);
         // ---- close the block when it is large enough or the chunk ends -------------
-        const uint32_t covered = L.entry;   // every byte below is inside an emitted token
         if (replay) {
             if (tail) {
+                WG_SYNC();   // (close_block reads what the first lane has just written)
                 close_block(L, n_eff, blk_tab, blk_hist);
                 b0 = n_eff;
                 blk++;
@@ -1473,7 +1478,7 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
             // histograms, and the number of observations is the number of token units.
             bool split = false;
             {
-                const uint32_t n_old = L.n_obs_old, n_new = L.block_ntok - n_old;
+                const uint32_t n_old = L.n_obs_old, n_new = open_ntok - n_old;
                 const uint32_t block_len = covered - L.block_start;
                 if (lp.split && !tail && n_new >= kObsPerCheck && n - covered > kMinBlock && block_len >= kMinBlock) {
                     if (tid < kObsTypes) {
@@ -1504,8 +1509,9 @@ __device__ uint32_t compress_chunk(ChunkLds &L, const uint8_t *in, uint32_t n, L
                     }
                 }
             }
-            if (tail || split || covered - L.block_start >= kBlockSoft || L.block_ntok + 3 * kCT + 4 > kTokCap) {
+            if (tail || split || covered - L.block_start >= kBlockSoft || open_ntok + 3 * kCT + 4 > kTokCap) {
                 const uint32_t block_end = tail ? n : covered;
+                WG_SYNC();   // (both read what the first lane has just written)
                 if (analysis) record_block(L, block_end, blkcost);
                 else close_block(L, block_end, blk_tab, blk_hist);
             } else if (analysis) {

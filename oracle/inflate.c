@@ -339,6 +339,11 @@ static void load_static_codes(inflater *d)
                        d->sorted_syms, &d->litlen_tablebits);
 }
 
+/* tools that study token statistics compile this file with their own ORC_ON_MATCH(position, length, offset) */
+#ifndef ORC_ON_MATCH
+#define ORC_ON_MATCH(o, length, offset)
+#endif
+
 /* careful loop of src/decompress/mod.rs:940-1071 (the fast loops at :629-770
  * and :778-938 decode the same symbols with the same refill points) */
 static int huffman_block(inflater *d, bitreader *b, uint8_t *out, size_t out_len, size_t *out_idx)
@@ -413,6 +418,7 @@ static int huffman_block(inflater *d, bitreader *b, uint8_t *out, size_t out_len
             return ORC_BAD_DATA;
         if (o + length > out_len)
             return ORC_INSUFFICIENT_SPACE;
+        ORC_ON_MATCH(o, length, offset);
         /* every copy specialisation in the reference equals this byte-serial
          * copy (overlap repeats the last `offset` bytes) */
         const uint8_t *src = out + o - offset;
