@@ -1228,20 +1228,25 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
     uint16_t *ptr = reinterpret_cast<uint16_t *>(L.win);
     // A pointer is the source position minus sub_start, modulo 2^16: [0, kCopySub) points into the
     // step (and may still move), [kLanded, kLanded + kCopySub) into the step at a byte known to be a
-    // literal, [2^16 - 32768 - kCopySub, 2^16) in front of the step.  kSelf (a literal: nothing to
-    // copy) lies in none of these ranges.
-    constexpr uint32_t kSelf = 0x6000;
+    // literal, [2^16 - 32768 - kCopySub, 2^16) in front of the step.  The slot of a literal (nothing to
+    // copy) holds the landed pointer to itself, so whoever jumps to it is settled by taking the slot's
+    // value like any other.
     constexpr uint32_t kLanded = 0x4000;
     constexpr uint32_t kFront = 0x10000 - 32768 - kCopySub;   // smallest pointer to a byte in front of the step
-    static_assert(kLanded >= kCopySub && kLanded + kCopySub <= kSelf && kSelf < kFront, "pointer ranges are disjoint");
+    static_assert(kLanded >= kCopySub && kLanded + kCopySub < kFront, "pointer ranges are disjoint");
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     uint32_t mcur = 0;                  // first queued match that reaches into the current step (uniform)
-    if (tid == 0) ptr[kCopySub] = (uint16_t)kSelf;   // the spare slot (a pad word of the window buffer)
-    // every step starts from a table of kSelf; a step clears it for the next one as soon as its own
-    // pointers are in registers
-    static_assert(kCopySub == kT * 8, "one 16-byte store per lane clears the pointers");
-    const uint4 all_self = make_uint4(kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u, kSelf * 0x10001u);
-    reinterpret_cast<uint4 *>(ptr)[tid] = all_self;
+    if (tid == 0) ptr[kCopySub] = (uint16_t)kLanded;   // the spare slot (a pad word of the window buffer): read by settled bytes, never used
+    // every step starts from a table of self pointers; a step restores it for the next one as soon as
+    // its own pointers are in registers
+    static_assert(kCopySub == kT * 8, "one 16-byte store per lane restores the pointers");
+    // (worked out where it is stored, from a lane number the compiler cannot see through: kept in registers
+    // across the steps, these and the eight self pointers of the gather cost the kernel a workgroup per CU)
+    auto restore_table = [&](uint32_t t) {
+        const uint32_t self0 = (kLanded + 8u * t) * 0x10001u + 0x10000u;   // slots 8 t, 8 t + 1
+        reinterpret_cast<uint4 *>(ptr)[t] = make_uint4(self0, self0 + 0x20002u, self0 + 0x40004u, self0 + 0x60006u);
+    };
+    restore_table((uint32_t)tid);
     WG_SYNC();
     // a match that runs from one step into the next: the second step finds its distance and
     // length here (its first bytes in the ring are data by then); slots alternate between steps
@@ -1308,16 +1313,15 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         for (int k = 0; k < kT / 64; k++) mcur += L.scan_carry[k];
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[0] += t - tc; tc = t; }
         if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(15, t - ts); ts = t; SPLIT_T_ADD(19, 1); }
-        // Pointer jumping: a pointer into this step that lands on a non-literal byte takes
-        // over that byte's pointer.  Every lane keeps the pointers of its own kPer bytes in
-        // registers.  A pointer can still move while it points into the step (v < kCopySub)
-        // and is not known to have landed on a literal; one that has is marked with kLanded,
-        // in the table too, so whoever takes it over is settled at once.  The rounds are branch-free: settled bytes
+        // Pointer jumping: a pointer into this step takes over the pointer of the byte it points at: a
+        // literal's is the landed pointer to that literal, a match byte's is wherever that byte has got
+        // to.  Every lane keeps the pointers of its own kPer bytes in registers.  A pointer can still
+        // move while it points into the step (v < kCopySub).  The rounds are branch-free: settled bytes
         // read a spare slot behind the table and rewrite their own value.
         constexpr int kPer = kCopySub / kT;
         uint32_t v[kPer];
 #pragma unroll
-        for (int k = 0; k < kPer; k++) v[k] = ptr[tid + k * kT];   // slots behind n hold kSelf
+        for (int k = 0; k < kPer; k++) v[k] = ptr[tid + k * kT];   // slots behind the step's end point at themselves
         for (int round = 0; round < 16; round++) {
             uint32_t v2[kPer];
             if (RSX_DEV_TIMERS && tid == 0) L.stat_copy++;
@@ -1336,8 +1340,7 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
                 const bool pending = v[k] < kCopySub;
-                const uint32_t nv = v2[k] == kSelf ? v[k] | kLanded : v2[k];
-                v[k] = pending ? nv : v[k];
+                v[k] = pending ? v2[k] : v[k];
                 ptr[tid + k * kT] = (uint16_t)v[k];
                 moving = moving || v[k] < kCopySub;
             }
@@ -1355,7 +1358,9 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         }
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[2] += t - tc; tc = t; }
         if (RSX_SPLIT_TIMERS && tid == 0) { unsigned long long t = SPLIT_T_NOW(); SPLIT_T_ADD(16, t - ts); ts = t; }
-        reinterpret_cast<uint4 *>(ptr)[tid] = all_self;   // (nobody reads the table any more in this step)
+        uint32_t lane_no = (uint32_t)tid;
+        asm volatile("" : "+v"(lane_no));
+        restore_table(lane_no);   // (nobody reads the table any more in this step)
         // gather: sources are literals of this step, earlier bytes of the round (ring) or
         // bytes that have left the ring (read back from the output)
         {
@@ -1368,7 +1373,8 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
             for (int k = 0; k < kPer; k++) {
                 // (32-bit positions) in front of the step, or a literal of the step
                 sp[k] = sub_start + v[k] - (v[k] >= kFront ? 0x10000u : kLanded);
-                far[k] = v[k] != kSelf && round_end - sp[k] > kRing;
+                // (a slot that points at itself is a literal or lies behind the step's end: nothing to fetch)
+                far[k] = v[k] - (kLanded + k * kT) != lane_no && round_end - sp[k] > kRing;
             }
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
@@ -1379,7 +1385,8 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
             for (int k = 0; k < kPer; k++) byte[k] = L.ring[(sp[k] + c.shift) & kRingMask];   // (an LDS read, never a flat one)
 #pragma unroll
             for (int k = 0; k < kPer; k++)
-                if (v[k] != kSelf) L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = far[k] ? far_byte[k] : byte[k];
+                if (v[k] - (kLanded + k * kT) != lane_no)   // (not a literal, and not a slot behind the step's end)
+                    L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = far[k] ? far_byte[k] : byte[k];
         }
         WG_SYNC();
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tc; tc = t; }
