@@ -1365,28 +1365,32 @@ __device__ void copy_round(LS &L, const StreamCtx &c)
         // bytes that have left the ring (read back from the output)
         {
             // sources that have left the ring are read back from the output: every such load of a lane is
-            // issued before the first one is waited for (one memory latency per step, not one per byte)
-            uint32_t sp[kPer];
+            // issued before the first one is waited for (one memory latency per step, not one per byte).
+            // A settled pointer v stands for position sub_start + v - 0x10000 (in front of the step) or
+            // sub_start + v - kLanded (a literal of the step): both offsets are multiples of the ring's size,
+            // so the byte's place in the ring is (sub_start + v) mod kRing for either, and "has left the
+            // ring" (more than kRing in front of the round's end, which only a pointer to the front can be)
+            // is one range test on v.
+            static_assert(kLanded % kRing == 0 && 0x10000 % kRing == 0, "one ring index for both kinds of pointer");
+            const uint32_t ring_base = sub_start + c.shift;
+            const uint32_t far_span = round_end - sub_start + 0x10000u - kRing - kFront;   // (> 0)
+            const __attribute__((address_space(1))) uint8_t *const far_base =
+                (const __attribute__((address_space(1))) uint8_t *)c.out + sub_start - 0x10000;
             uint8_t far_byte[kPer], byte[kPer];
             bool far[kPer];
 #pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                // (32-bit positions) in front of the step, or a literal of the step
-                sp[k] = sub_start + v[k] - (v[k] >= kFront ? 0x10000u : kLanded);
-                // (a slot that points at itself is a literal or lies behind the step's end: nothing to fetch)
-                far[k] = v[k] - (kLanded + k * kT) != lane_no && round_end - sp[k] > kRing;
-            }
+            for (int k = 0; k < kPer; k++) far[k] = v[k] - kFront < far_span;
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
                 far_byte[k] = 0;
-                if (far[k]) far_byte[k] = *((const __attribute__((address_space(1))) uint8_t *)c.out + sp[k]);
+                if (far[k]) far_byte[k] = far_base[v[k]];
             }
 #pragma unroll
-            for (int k = 0; k < kPer; k++) byte[k] = L.ring[(sp[k] + c.shift) & kRingMask];   // (an LDS read, never a flat one)
+            for (int k = 0; k < kPer; k++) byte[k] = L.ring[(ring_base + v[k]) & kRingMask];   // (an LDS read, never a flat one)
 #pragma unroll
             for (int k = 0; k < kPer; k++)
                 if (v[k] - (kLanded + k * kT) != lane_no)   // (not a literal, and not a slot behind the step's end)
-                    L.ring[(sub_start + tid + k * kT + c.shift) & kRingMask] = far[k] ? far_byte[k] : byte[k];
+                    L.ring[(ring_base + lane_no + k * kT) & kRingMask] = far[k] ? far_byte[k] : byte[k];
         }
         WG_SYNC();
         if (RSX_DEV_TIMERS == 2 && tid == 0) { unsigned long long t = clock64(); L.stat_t[3] += t - tc; tc = t; }
