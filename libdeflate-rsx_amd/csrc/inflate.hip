@@ -1769,7 +1769,7 @@ constexpr uint32_t kTokCap = 96 * (kT / kDT);   // tokens per sub-sequence and r
 constexpr uint32_t kSegSteps = 16;        // the expander walks a sub-sequence in pieces of this many steps
 constexpr uint32_t kSegRows = kTokCap / kSegSteps - 1;   // header rows 1..kSegRows: bytes | matches << 16 in front of piece p
 constexpr uint32_t kHdrRows = 1 + kSegRows;
-static_assert(kTokCap % kSegSteps == 0, "whole pieces");
+static_assert(kTokCap % kSegSteps == 0 && (kSegSteps & (kSegSteps - 1)) == 0, "whole pieces, and the piece of a token is found by masking");
 #ifndef RSX_LANE_BYTES
 #define RSX_LANE_BYTES 8192
 #endif
