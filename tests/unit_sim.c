@@ -1,6 +1,6 @@
 /* How deep are the dependencies between the matches of a DEFLATE stream when its output is produced in groups
  * and every match is cut into pieces of at most 16 bytes that are copied as soon as their source bytes are
- * final?  tools/unit_sim <raw deflate file> <output size> [group bytes] [unit cap]: rounds per group, pieces
+ * final?  tests/unit_sim <raw deflate file> <output size> [group bytes] [unit cap]: rounds per group, pieces
  * visited per round.  (CPU; a model of a copy phase that was considered for the expand kernel.) */
 #include <stdint.h>
 #include <stdio.h>
